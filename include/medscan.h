@@ -1,0 +1,123 @@
+/*
+ * medscan.h -- C ABI of libmedscan.so (MI355X / gfx950 selective-scan hot path).
+ *
+ * This is the drop-in boundary for the reference's native extension `selective_scan_cuda`
+ * (pybind module, /root/reference/CrossMamba/FusionMamba/selective_scan/selective_scan.cpp:494-497)
+ * and for the eager tensor ops around it inside SS2D (/root/reference/MedMamba.py:386-424,466-483).
+ *
+ *   - plain pointers + sizes + element strides, no torch / ATen types;
+ *   - caller owns every buffer (outputs pre-allocated; gradient accumulators that are reduced with
+ *     atomics -- dA, dB, dC, dD, ddelta_bias -- must be ZEROED by the caller before the call, like the
+ *     reference's `torch::zeros_like`, selective_scan.cpp:460-466);
+ *   - all work is enqueued on the `stream` argument (a hipStream_t passed as void*); no host
+ *     synchronisation, no allocation, no global state -> re-entrant per stream and graph-capturable;
+ *   - return value: MS_OK (0) or a negative MsStatus; nothing is thrown across the ABI.
+ *
+ * dtype: all tensors are fp32 (the reference's kernels compute in fp32 for every I/O dtype,
+ * selective_scan_fwd_kernel.cuh:147-160; SS2D hard-casts the scan operands to fp32, MedMamba.py:403-409).
+ */
+#ifndef MEDSCAN_H_
+#define MEDSCAN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEDSCAN_ABI_VERSION 1
+
+typedef enum MsStatus {
+    MS_OK = 0,
+    MS_ERR_NULL = -1,        /* a required pointer is NULL                                  */
+    MS_ERR_SHAPE = -2,       /* non-positive size, dim % n_groups != 0, ...                  */
+    MS_ERR_DSTATE = -3,      /* dstate > 256 (selective_scan.cpp:262) or not tileable        */
+    MS_ERR_STRIDE = -4,      /* unsupported stride combination                               */
+    MS_ERR_LAUNCH = -5,      /* hipLaunchKernel failed (hipGetLastError is left set)         */
+    MS_ERR_UNSUPPORTED = -6  /* feature not built (complex A, constant B/C inside the kernel)*/
+} MsStatus;
+
+/* Sequence positions between two saved states of the forward recurrence (the reference uses 2048,
+ * selective_scan.cpp:307; the value is private to the implementation as long as fwd and bwd agree). */
+#define MS_SCAN_CHUNK 32
+
+/*
+ * Launch parameters of the selective scan; the field set of the reference's SSMParamsBase
+ * (selective_scan.h:26-69) with int64 element strides, an explicit sequence stride for every
+ * activation (so (B,D,L) and channel-last (B,L,D) tensors are both first-class) and no z/complex.
+ *
+ *   u, delta, out : logical shape (batch, dim, seqlen)
+ *   A             : (dim, dstate)                         fp32, real
+ *   B, C          : (batch, n_groups, dstate, seqlen)     channel d uses group d / (dim / n_groups)
+ *   D, delta_bias : (dim) contiguous, may be NULL
+ *   x             : saved states, contiguous (batch, n_chunks, dstate, dim) with
+ *                   n_chunks = ms_scan_n_chunks(seqlen); x[b,c,n,d] = h after position
+ *                   min((c+1)*MS_SCAN_CHUNK, seqlen)-1.   May be NULL in forward (inference).
+ *                   (reference: x (batch,dim,n_chunks,2*dstate), selective_scan.cpp:313; the layout is
+ *                   private to the extension there too, selective_scan_interface.py:46 only reads the
+ *                   last state, which here is x[:, n_chunks-1].)
+ */
+typedef struct MsScanParams {
+    int32_t batch, dim, seqlen, dstate, n_groups;
+    int32_t delta_softplus;                 /* bool */
+    int64_t u_batch_stride, u_d_stride, u_l_stride;
+    int64_t delta_batch_stride, delta_d_stride, delta_l_stride;
+    int64_t out_batch_stride, out_d_stride, out_l_stride;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride, B_l_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride, C_l_stride;
+    const float *u, *delta, *A, *B, *C, *D, *delta_bias;
+    float *out;
+    float *x;
+} MsScanParams;
+
+/*
+ * Backward; field set of SSMParamsBwd (selective_scan.h:71-101).
+ *   dout, du, ddelta : (batch, dim, seqlen) with their own strides
+ *   dA (dim,dstate) contiguous; dB, dC (batch,n_groups,dstate,seqlen) contiguous fp32;
+ *   dD, ddelta_bias (dim) or NULL.  dA/dB/dC/dD/ddelta_bias are ACCUMULATED INTO (atomics).
+ *   x is required when seqlen > MS_SCAN_CHUNK.
+ */
+typedef struct MsScanBwdParams {
+    MsScanParams f;                          /* forward operands; f.out is unused, f.x is read */
+    int64_t dout_batch_stride, dout_d_stride, dout_l_stride;
+    int64_t du_batch_stride, du_d_stride, du_l_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride, ddelta_l_stride;
+    const float *dout;
+    float *du, *ddelta, *dA, *dB, *dC, *dD, *ddelta_bias;
+} MsScanBwdParams;
+
+/* replaces selective_scan_cuda.fwd  (selective_scan.cpp:226-336 -> selective_scan_fwd_kernel.cuh:67-303) */
+int ms_selective_scan_fwd(const MsScanParams *p, void *stream);
+/* replaces selective_scan_cuda.bwd  (selective_scan.cpp:338-492 -> selective_scan_bwd_kernel.cuh:75-489) */
+int ms_selective_scan_bwd(const MsScanBwdParams *p, void *stream);
+/* number of saved states per row for a sequence length (host-side sizing of `x`) */
+int ms_scan_n_chunks(int seqlen);
+
+/*
+ * 4-direction cross-scan and cross-merge (MedMamba.py:393-395 and :420-424,476), fp32, contiguous.
+ *   cross_scan : x (batch, dim, H, W)      -> xs (batch, 4, dim, H*W)
+ *   cross_merge: ys (batch, 4, dim, H*W)   -> y  (batch, dim, H*W) = ((y0 + flip(y2)) + T(y1)) + T(flip(y3))
+ * Each is the other's adjoint, so the same two entry points serve the backward pass.
+ */
+int ms_cross_scan(const float *x, float *xs, int batch, int dim, int H, int W, void *stream);
+int ms_cross_merge(const float *ys, float *y, int batch, int dim, int H, int W, void *stream);
+
+/*
+ * Depthwise 3x3 conv (padding 1, stride 1) + bias + SiLU, NCHW fp32 contiguous
+ * (nn.Conv2d(groups=C) followed by nn.SiLU, MedMamba.py:285-294,473).
+ *   fwd: y = silu(conv(x, w) + bias)          x,y (batch, C, H, W); w (C,1,3,3); bias (C) or NULL
+ *   bwd: given dy, recomputes the pre-activation; writes dx; ACCUMULATES dw (C,9) and dbias (C).
+ */
+int ms_dwconv3x3_silu_fwd(const float *x, const float *w, const float *bias, float *y,
+                          int batch, int C, int H, int W, void *stream);
+int ms_dwconv3x3_silu_bwd(const float *x, const float *w, const float *bias, const float *dy,
+                          float *dx, float *dw, float *dbias, int batch, int C, int H, int W, void *stream);
+
+int ms_abi_version(void);
+const char *ms_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDSCAN_H_ */

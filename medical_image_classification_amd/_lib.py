@@ -1,0 +1,113 @@
+"""ctypes binding of libmedscan.so (the C ABI declared in include/medscan.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If it is missing, cannot be
+loaded, or a call returns a non-zero status, a RuntimeError is raised -- loudly, never silently.
+PyTorch is used only for device memory and streams: every call passes raw `data_ptr()`s plus the
+current HIP stream, so the kernels are ordered with the surrounding torch ops and are graph-capturable.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmedscan.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+
+
+class MsScanParams(ctypes.Structure):
+    """Mirror of `MsScanParams` (include/medscan.h); field set of the reference's SSMParamsBase
+    (selective_scan.h:26-69)."""
+    _fields_ = (
+        [(n, c_i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "delta_softplus")]
+        + [(n, c_i64) for n in (
+            "u_batch_stride", "u_d_stride", "u_l_stride",
+            "delta_batch_stride", "delta_d_stride", "delta_l_stride",
+            "out_batch_stride", "out_d_stride", "out_l_stride",
+            "A_d_stride", "A_dstate_stride",
+            "B_batch_stride", "B_group_stride", "B_dstate_stride", "B_l_stride",
+            "C_batch_stride", "C_group_stride", "C_dstate_stride", "C_l_stride")]
+        + [(n, c_vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "out", "x")]
+    )
+
+
+class MsScanBwdParams(ctypes.Structure):
+    """Mirror of `MsScanBwdParams`; field set of SSMParamsBwd (selective_scan.h:71-101)."""
+    _fields_ = (
+        [("f", MsScanParams)]
+        + [(n, c_i64) for n in (
+            "dout_batch_stride", "dout_d_stride", "dout_l_stride",
+            "du_batch_stride", "du_d_stride", "du_l_stride",
+            "ddelta_batch_stride", "ddelta_d_stride", "ddelta_l_stride")]
+        + [(n, c_vp) for n in ("dout", "du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias")]
+    )
+
+
+EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_cross_scan",
+           "ms_cross_merge", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_abi_version",
+           "ms_status_string")
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libmedscan.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError if the library is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError(
+            f"{_SO} is missing: the MI355X selective-scan kernels are not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+            "medical_image_classification_amd/csrc`). There is no CPU fallback in the product path.")
+    try:
+        h = ctypes.CDLL(_SO)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {_SO}: {e}") from e
+    for name in EXPORTS:
+        if not hasattr(h, name):
+            raise RuntimeError(f"{_SO} does not export {name}")
+    h.ms_selective_scan_fwd.argtypes = [ctypes.POINTER(MsScanParams), c_vp]
+    h.ms_selective_scan_bwd.argtypes = [ctypes.POINTER(MsScanBwdParams), c_vp]
+    h.ms_scan_n_chunks.argtypes = [ctypes.c_int]
+    h.ms_cross_scan.argtypes = [c_vp, c_vp] + [ctypes.c_int] * 4 + [c_vp]
+    h.ms_cross_merge.argtypes = [c_vp, c_vp] + [ctypes.c_int] * 4 + [c_vp]
+    h.ms_dwconv3x3_silu_fwd.argtypes = [c_vp] * 4 + [ctypes.c_int] * 4 + [c_vp]
+    h.ms_dwconv3x3_silu_bwd.argtypes = [c_vp] * 7 + [ctypes.c_int] * 4 + [c_vp]
+    h.ms_status_string.restype = ctypes.c_char_p
+    h.ms_status_string.argtypes = [ctypes.c_int]
+    for name in EXPORTS[:-1]:
+        getattr(h, name).restype = ctypes.c_int
+    if h.ms_abi_version() != 1:
+        raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != 1 (stale build?)")
+    _lib = h
+    return h
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {lib().ms_status_string(status).decode()} (status {status})")
+
+
+def current_stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "medical_image_classification_amd: this operator runs only on an MI355X (HIP) device; got a "
+                f"{t.device} tensor. There is no CPU fallback in the product path (the CPU oracle lives in "
+                "oracle/ and is test infrastructure).")

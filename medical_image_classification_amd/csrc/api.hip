@@ -1,0 +1,64 @@
+// extern "C" entry points of libmedscan.so (see include/medscan.h for the contract and the
+// reference interfaces each one replaces).
+#include <hip/hip_runtime.h>
+#include "medscan.h"
+
+namespace ms {
+int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream);
+int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream);
+int cross_scan_dispatch(const float *x, float *xs, int batch, int dim, int H, int W, hipStream_t s);
+int cross_merge_dispatch(const float *ys, float *y, int batch, int dim, int H, int W, hipStream_t s);
+int dwconv_fwd_dispatch(const float *x, const float *w, const float *bias, float *y,
+                        int batch, int C, int H, int W, hipStream_t s);
+int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const float *dy, float *dx,
+                        float *dw, float *dbias, int batch, int C, int H, int W, hipStream_t s);
+}  // namespace ms
+
+extern "C" {
+
+int ms_selective_scan_fwd(const MsScanParams *p, void *stream) {
+    if (!p) return MS_ERR_NULL;
+    return ms::scan_fwd_dispatch(*p, (hipStream_t)stream);
+}
+
+int ms_selective_scan_bwd(const MsScanBwdParams *p, void *stream) {
+    if (!p) return MS_ERR_NULL;
+    return ms::scan_bwd_dispatch(*p, (hipStream_t)stream);
+}
+
+int ms_scan_n_chunks(int seqlen) { return seqlen <= 0 ? 0 : (seqlen + MS_SCAN_CHUNK - 1) / MS_SCAN_CHUNK; }
+
+int ms_cross_scan(const float *x, float *xs, int batch, int dim, int H, int W, void *stream) {
+    return ms::cross_scan_dispatch(x, xs, batch, dim, H, W, (hipStream_t)stream);
+}
+
+int ms_cross_merge(const float *ys, float *y, int batch, int dim, int H, int W, void *stream) {
+    return ms::cross_merge_dispatch(ys, y, batch, dim, H, W, (hipStream_t)stream);
+}
+
+int ms_dwconv3x3_silu_fwd(const float *x, const float *w, const float *bias, float *y,
+                          int batch, int C, int H, int W, void *stream) {
+    return ms::dwconv_fwd_dispatch(x, w, bias, y, batch, C, H, W, (hipStream_t)stream);
+}
+
+int ms_dwconv3x3_silu_bwd(const float *x, const float *w, const float *bias, const float *dy,
+                          float *dx, float *dw, float *dbias, int batch, int C, int H, int W, void *stream) {
+    return ms::dwconv_bwd_dispatch(x, w, bias, dy, dx, dw, dbias, batch, C, H, W, (hipStream_t)stream);
+}
+
+int ms_abi_version(void) { return MEDSCAN_ABI_VERSION; }
+
+const char *ms_status_string(int status) {
+    switch (status) {
+        case MS_OK: return "ok";
+        case MS_ERR_NULL: return "required pointer is NULL";
+        case MS_ERR_SHAPE: return "invalid shape";
+        case MS_ERR_DSTATE: return "unsupported state dimension";
+        case MS_ERR_STRIDE: return "unsupported strides";
+        case MS_ERR_LAUNCH: return "kernel launch failed";
+        case MS_ERR_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown status";
+}
+
+}  // extern "C"
