@@ -1,0 +1,348 @@
+"""MedMamba module surface on the MI355X kernels.
+
+Same class names, constructor arguments, forward signatures and state_dict keys/shapes as the reference's
+MedMamba.py (PatchEmbed2D :146, PatchMerging2D :172, SS2D :253, channel_shuffle :486, SS_Conv_SSM :502,
+VSSLayer :541, VSSM :671), so checkpoints written by the reference's train.py:103 / ddp_train.py:188-194 load
+here unchanged and downstream model files can `from ... import VSSM as medmamba` (train.py:11).
+`VSSBlock` and `MedMamba` are aliases for SS_Conv_SSM / VSSM (the names BASELINE.json's north_star uses).
+
+What is different is underneath SS2D.forward: the depthwise conv + SiLU, the 4-direction cross-scan, the
+selective scan (fwd/bwd) and the cross-merge are hand-written gfx950 kernels reached through the C ABI
+(include/medscan.h); there is no CPU path -- CPU tensors raise RuntimeError.
+"""
+import math
+from functools import partial
+from typing import Callable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from . import _lib
+from .selective_scan_interface import selective_scan_fn
+from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (the reference takes it from timm: MedMamba.py:11,515)."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob}"
+
+
+class PatchEmbed2D(nn.Module):
+    """Image (B,C,H,W) -> tokens (B,H/p,W/p,embed_dim): strided conv + optional norm (MedMamba.py:146-169)."""
+
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None, **kwargs):
+        super().__init__()
+        if isinstance(patch_size, int):
+            patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        x = self.proj(x).permute(0, 2, 3, 1)
+        return x if self.norm is None else self.norm(x)
+
+
+class PatchMerging2D(nn.Module):
+    """2x2 neighbourhood -> channels, LayerNorm(4C), Linear(4C->2C) (MedMamba.py:172-212)."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        h2, w2 = H // 2, W // 2
+        if (W % 2 != 0) or (H % 2 != 0):
+            print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
+        # order of the four taps as in the reference: (0,0), (1,0), (0,1), (1,1)
+        taps = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+        x = torch.cat(taps, dim=-1).view(B, h2, w2, 4 * C)
+        return self.reduction(self.norm(x))
+
+
+class SS2D(nn.Module):
+    """2-D selective scan block (MedMamba.py:253-483).  Parameters / state_dict keys:
+    in_proj.weight (2D,d_model); conv2d.{weight (D,1,3,3), bias (D)}; x_proj_weight (4,R+2N,D);
+    dt_projs_weight (4,D,R); dt_projs_bias (4,D); A_logs (4D,N); Ds (4D); out_norm.{weight,bias} (D);
+    out_proj.weight (d_model,D)."""
+
+    def __init__(self, d_model, d_state=16, d_conv=3, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, dropout=0., conv_bias=True, bias=False,
+                 device=None, dtype=None, **kwargs):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model = d_model
+        self.d_state = d_state
+        self.d_conv = d_conv
+        self.expand = expand
+        self.d_inner = int(self.expand * self.d_model)
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+        K, D, N, R = 4, self.d_inner, self.d_state, self.dt_rank
+
+        self.in_proj = nn.Linear(self.d_model, 2 * D, bias=bias, **fk)
+        self.conv2d = nn.Conv2d(D, D, groups=D, bias=conv_bias, kernel_size=d_conv, padding=(d_conv - 1) // 2, **fk)
+        self.act = nn.SiLU()
+
+        # four independent x_proj / dt_proj matrices, stored stacked (MedMamba.py:296-317)
+        bound = 1.0 / math.sqrt(D)                      # nn.Linear default init of the four x_proj layers
+        self.x_proj_weight = nn.Parameter(torch.empty(K, R + 2 * N, D, **fk).uniform_(-bound, bound))
+        w, b = zip(*[self.dt_init(R, D, dt_scale, dt_init, dt_min, dt_max, dt_init_floor, **fk) for _ in range(K)])
+        self.dt_projs_weight = nn.Parameter(torch.stack(w, dim=0))    # (K, D, R)
+        self.dt_projs_bias = nn.Parameter(torch.stack(b, dim=0))      # (K, D)
+        self.A_logs = self.A_log_init(N, D, copies=K, merge=True)     # (K*D, N)
+        self.Ds = self.D_init(D, copies=K, merge=True)                # (K*D)
+
+        self.forward_core = self.forward_corev0      # reassignable hook, as in the reference (:323)
+        self.out_norm = nn.LayerNorm(D)
+        self.out_proj = nn.Linear(D, self.d_model, bias=bias, **fk)
+        self.dropout = nn.Dropout(dropout) if dropout > 0. else None
+
+    # ---- initialisers (MedMamba.py:329-384) --------------------------------------------------------
+    @staticmethod
+    def dt_init(dt_rank, d_inner, dt_scale=1.0, dt_init="random", dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4,
+                **fk):
+        """Returns (weight (d_inner, dt_rank), bias (d_inner)) of one dt projection: weight U(+-R^-0.5*scale)
+        (or constant), bias = softplus^-1(dt) with dt log-uniform in [dt_min, dt_max], floored."""
+        std = dt_rank ** -0.5 * dt_scale
+        weight = torch.empty(d_inner, dt_rank, **fk)
+        if dt_init == "constant":
+            weight.fill_(std)
+        elif dt_init == "random":
+            weight.uniform_(-std, std)
+        else:
+            raise NotImplementedError
+        dt = torch.exp(torch.rand(d_inner, **fk) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min))
+        dt = dt.clamp(min=dt_init_floor)
+        bias = dt + torch.log(-torch.expm1(-dt))      # inverse softplus
+        return weight, bias
+
+    @staticmethod
+    def A_log_init(d_state, d_inner, copies=1, device=None, merge=True):
+        A_log = torch.log(torch.arange(1, d_state + 1, dtype=torch.float32, device=device)).repeat(d_inner, 1)
+        if copies > 1:
+            A_log = A_log.unsqueeze(0).repeat(copies, 1, 1)
+            if merge:
+                A_log = A_log.flatten(0, 1)
+        A_log = nn.Parameter(A_log.contiguous())
+        A_log._no_weight_decay = True
+        return A_log
+
+    @staticmethod
+    def D_init(d_inner, copies=1, device=None, merge=True):
+        D = torch.ones(d_inner, device=device)
+        if copies > 1:
+            D = D.unsqueeze(0).repeat(copies, 1)
+            if merge:
+                D = D.flatten(0, 1)
+        D = nn.Parameter(D)
+        D._no_weight_decay = True
+        return D
+
+    # ---- scan operands (MedMamba.py:397-409) -------------------------------------------------------
+    def _scan_operands(self, xs):
+        """xs (B,4,D,L) -> selective-scan operands; B/C stay strided views of x_dbl (no copies)."""
+        B, K, D, L = xs.shape
+        N, R = self.d_state, self.dt_rank
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        return (xs.float().view(B, K * D, L), dts.contiguous().float().view(B, K * D, L),
+                -torch.exp(self.A_logs.float()).view(K * D, N), Bs.float(), Cs.float(),
+                self.Ds.float().view(-1), self.dt_projs_bias.float().view(-1))
+
+    def _scan(self, x):
+        """x (B,D,H,W) after conv+SiLU -> per-direction scan outputs (B,4,D,L), fp32."""
+        B, D, H, W = x.shape
+        xs = cross_scan(x)
+        u, dts, As, Bs, Cs, Ds, dt_bias = self._scan_operands(xs)
+        out_y = self.selective_scan(u, dts, As, Bs, Cs, Ds, z=None, delta_bias=dt_bias, delta_softplus=True,
+                                    return_last_state=False).view(B, 4, D, H * W)
+        assert out_y.dtype == torch.float
+        return out_y
+
+    def forward_corev0(self, x: torch.Tensor):
+        """Reference hook contract (MedMamba.py:386-424): x (B,C,H,W) -> four (B,C,L) tensors whose sum is the
+        merged result.  SS2D.forward itself uses the fused merge kernel instead of materialising these."""
+        self.selective_scan = selective_scan_fn
+        B, C, H, W = x.shape
+        L = H * W
+        out_y = self._scan(x)
+        inv_y = torch.flip(out_y[:, 2:4], dims=[-1])
+        wh_y = out_y[:, 1].view(B, C, W, H).transpose(2, 3).contiguous().view(B, C, L)
+        invwh_y = inv_y[:, 1].view(B, C, W, H).transpose(2, 3).contiguous().view(B, C, L)
+        return out_y[:, 0], inv_y[:, 0], wh_y, invwh_y
+
+    def forward(self, x: torch.Tensor, **kwargs):
+        _lib.require_cuda(x)
+        B, H, W, C = x.shape
+        xz = self.in_proj(x)
+        x, z = xz.chunk(2, dim=-1)                                  # (B,H,W,D) each
+        x = x.permute(0, 3, 1, 2).contiguous()
+        x = dwconv3x3_silu(x, self.conv2d.weight, self.conv2d.bias)  # (B,D,H,W) fp32
+        if getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0:
+            self.selective_scan = selective_scan_fn
+            y = cross_merge(self._scan(x), H, W)                    # (B,D,L) = y1+y2+y3+y4, one kernel
+        else:                                                       # user-supplied core: reference data flow
+            y1, y2, y3, y4 = self.forward_core(x)
+            assert y1.dtype == torch.float32
+            y = y1 + y2 + y3 + y4
+        y = y.transpose(1, 2).contiguous().view(B, H, W, -1)
+        y = self.out_norm(y)
+        y = y * F.silu(z)
+        out = self.out_proj(y)
+        if self.dropout is not None:
+            out = self.dropout(out)
+        return out
+
+
+def channel_shuffle(x: torch.Tensor, groups: int) -> torch.Tensor:
+    """(B,H,W,C): interleave `groups` channel groups (MedMamba.py:486-499)."""
+    B, H, W, C = x.size()
+    return x.view(B, H, W, groups, C // groups).transpose(3, 4).contiguous().view(B, H, W, -1)
+
+
+class SS_Conv_SSM(nn.Module):
+    """Two-branch block: conv branch on the left half of the channels, LN + SS2D on the right half, concat,
+    shuffle, residual (MedMamba.py:502-538)."""
+
+    def __init__(self, hidden_dim: int = 0, drop_path: float = 0,
+                 norm_layer: Callable[..., torch.nn.Module] = partial(nn.LayerNorm, eps=1e-6),
+                 attn_drop_rate: float = 0, d_state: int = 16, **kwargs):
+        super().__init__()
+        half = hidden_dim // 2
+        self.ln_1 = norm_layer(half)
+        self.self_attention = SS2D(d_model=half, dropout=attn_drop_rate, d_state=d_state, **kwargs)
+        self.drop_path = DropPath(drop_path)
+        self.conv33conv33conv11 = nn.Sequential(
+            nn.BatchNorm2d(half),
+            nn.Conv2d(half, half, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(half),
+            nn.ReLU(),
+            nn.Conv2d(half, half, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(half),
+            nn.ReLU(),
+            nn.Conv2d(half, half, kernel_size=1, stride=1),
+            nn.ReLU(),
+        )
+
+    def forward(self, input: torch.Tensor):
+        left, right = input.chunk(2, dim=-1)
+        x = self.drop_path(self.self_attention(self.ln_1(right)))
+        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous())
+        left = left.permute(0, 2, 3, 1).contiguous()
+        out = channel_shuffle(torch.cat((left, x), dim=-1), groups=2)
+        return out + input
+
+
+class VSSLayer(nn.Module):
+    """One stage: `depth` blocks then an optional downsample (MedMamba.py:541-604)."""
+
+    def __init__(self, dim, depth, attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None,
+                 use_checkpoint=False, d_state=16, **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.use_checkpoint = use_checkpoint
+        self.blocks = nn.ModuleList([
+            SS_Conv_SSM(hidden_dim=dim, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                        norm_layer=norm_layer, attn_drop_rate=attn_drop, d_state=d_state)
+            for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
+        return x if self.downsample is None else self.downsample(x)
+
+
+class VSSM(nn.Module):
+    """MedMamba classifier (MedMamba.py:671-767).  Defaults = "MedMamba-T": depths [2,2,4,2],
+    dims [96,192,384,768], d_state 16."""
+
+    def __init__(self, patch_size=4, in_chans=3, num_classes=1000, depths=[2, 2, 4, 2], depths_decoder=[2, 9, 2, 2],
+                 dims=[96, 192, 384, 768], dims_decoder=[768, 384, 192, 96], d_state=16, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, patch_norm=True,
+                 use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        if isinstance(dims, int):
+            dims = [int(dims * 2 ** i) for i in range(self.num_layers)]
+        self.embed_dim = dims[0]
+        self.num_features = dims[-1]
+        self.dims = dims
+        self.patch_embed = PatchEmbed2D(patch_size=patch_size, in_chans=in_chans, embed_dim=self.embed_dim,
+                                        norm_layer=norm_layer if patch_norm else None)
+        self.ape = False
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [r.item() for r in torch.linspace(0, drop_path_rate, sum(depths))]   # stochastic-depth decay
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(VSSLayer(
+                dim=dims[i], depth=depths[i],
+                d_state=math.ceil(dims[0] / 6) if d_state is None else d_state,
+                drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                norm_layer=norm_layer,
+                downsample=PatchMerging2D if (i < self.num_layers - 1) else None,
+                use_checkpoint=use_checkpoint))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _init_weights(self, m: nn.Module):
+        """Linear: trunc_normal(.02) / zero bias; LayerNorm: (1, 0) (MedMamba.py:726-741).  The stacked
+        x_proj / dt_proj Parameters of SS2D are not nn.Linear and keep their own init."""
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"relative_position_bias_table"}
+
+    def forward_backbone(self, x):
+        x = self.pos_drop(self.patch_embed(x))
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def forward(self, x):
+        x = self.forward_backbone(x)
+        x = self.avgpool(x.permute(0, 3, 1, 2))
+        return self.head(torch.flatten(x, start_dim=1))
+
+
+# names used by BASELINE.json's north_star
+VSSBlock = SS_Conv_SSM
+MedMamba = VSSM

@@ -1,0 +1,119 @@
+"""torch.autograd wrappers of the non-scan HIP kernels on the SS2D path (C ABI: include/medscan.h).
+
+Each wrapper replaces a run of eager tensor ops of the reference's `SS2D`:
+  dwconv3x3_silu  <- `self.act(self.conv2d(x))`                         (MedMamba.py:285-294,473)
+  cross_scan      <- stack / transpose / flip / cat                      (MedMamba.py:393-395)
+  cross_merge     <- flips / transposes and `y1 + y2 + y3 + y4`          (MedMamba.py:420-424,476)
+cross_scan and cross_merge are each other's adjoint, so each one's backward is the other's forward.
+All of them need CUDA (HIP) tensors and raise RuntimeError otherwise -- no CPU fallback.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+class _CrossScan(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x):
+        _lib.require_cuda(x)
+        B, D, H, W = x.shape
+        x = x.contiguous()
+        xs = torch.empty((B, 4, D, H * W), device=x.device, dtype=torch.float32)
+        ctx.hw = (H, W)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_cross_scan(x.data_ptr(), xs.data_ptr(), B, D, H, W, _stream(x)), "ms_cross_scan")
+        return xs
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        H, W = ctx.hw
+        B, _, D, L = g.shape
+        g = g.contiguous().float()
+        dx = torch.empty((B, D, H, W), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().ms_cross_merge(g.data_ptr(), dx.data_ptr(), B, D, H, W, _stream(g)), "ms_cross_merge")
+        return dx
+
+
+class _CrossMerge(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, ys, H, W):
+        _lib.require_cuda(ys)
+        B, K, D, L = ys.shape
+        if K != 4 or L != H * W:
+            raise RuntimeError(f"cross_merge: expected (B,4,D,{H * W}), got {tuple(ys.shape)}")
+        ys = ys.contiguous()
+        y = torch.empty((B, D, L), device=ys.device, dtype=torch.float32)
+        ctx.hw = (H, W)
+        with torch.cuda.device(ys.device):
+            _lib.check(_lib.lib().ms_cross_merge(ys.data_ptr(), y.data_ptr(), B, D, H, W, _stream(ys)), "ms_cross_merge")
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        H, W = ctx.hw
+        B, D, L = g.shape
+        g = g.contiguous().float()
+        dys = torch.empty((B, 4, D, L), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().ms_cross_scan(g.data_ptr(), dys.data_ptr(), B, D, H, W, _stream(g)), "ms_cross_scan")
+        return dys, None, None
+
+
+class _DWConvSiLU(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias):
+        _lib.require_cuda(x, weight, bias)
+        B, C, H, W = x.shape
+        if tuple(weight.shape) != (C, 1, 3, 3):
+            raise RuntimeError(f"dwconv3x3_silu: weight must be ({C},1,3,3), got {tuple(weight.shape)}")
+        x, weight = x.contiguous(), weight.contiguous()
+        bias = bias.contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_dwconv3x3_silu_fwd(x.data_ptr(), weight.data_ptr(),
+                                                       bias.data_ptr() if bias is not None else None,
+                                                       y.data_ptr(), B, C, H, W, _stream(x)), "ms_dwconv3x3_silu_fwd")
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(weight)
+        db = torch.zeros_like(bias) if bias is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_dwconv3x3_silu_bwd(x.data_ptr(), weight.data_ptr(),
+                                                       bias.data_ptr() if bias is not None else None,
+                                                       dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                       db.data_ptr() if db is not None else None,
+                                                       B, C, H, W, _stream(x)), "ms_dwconv3x3_silu_bwd")
+        return dx, dw, db
+
+
+def cross_scan(x):
+    """(B, D, H, W) -> (B, 4, D, H*W): row-major, column-major and both reversed (MedMamba.py:393-395)."""
+    return _CrossScan.apply(x)
+
+
+def cross_merge(ys, H, W):
+    """(B, 4, D, H*W) -> (B, D, H*W) = ((y0 + flip(y2)) + T(y1)) + T(flip(y3)) (MedMamba.py:420-424,476)."""
+    return _CrossMerge.apply(ys, H, W)
+
+
+def dwconv3x3_silu(x, weight, bias):
+    """SiLU(depthwise conv3x3(x) + bias), NCHW (MedMamba.py:285-294,473)."""
+    return _DWConvSiLU.apply(x, weight, bias)
