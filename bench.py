@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one full training step (forward + backward + Adam) of MedMamba-T (depths [2,2,4,2], dims
+[96,192,384,768], d_state 16) on one synthetic batch of 64 3x224x224 images per GPU (BASELINE.json
+configs[1]; configs[3] for N > 1 = the same per-rank work under DDP over RCCL: weak scaling).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
+  value     = images/s of the whole job (N * 64 * K / max-over-ranks time)
+  roofline  = dominant hand-written kernel (the selective-scan backward): algorithmic bytes
+              (SURVEY.md section 8d formulas) / its HIP-event-measured duration inside the timed region,
+              against the 8 TB/s HBM3E peak; `traffic` = measured HBM bytes per launch from rocprofv3 PMC
+              passes when profiles/scan_traffic.json is present, else null
+  cpu_baseline = the CPU restatement of the same training step (oracle scan in C/OpenMP + torch CPU ops),
+              timed on this host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=64, help="per GPU (BASELINE.json: bs=64)")
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--num-classes", type=int, default=8)
+    ap.add_argument("--variant", default="T", choices=["T", "B"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="autocast dtype of the dense GEMM/conv ops; the scan is fp32 in both (MedMamba.py:403-409)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def host_cores():
+    """CPU cores this process may really use: min(affinity mask, cgroup CPU quota).  The GPU box shows 256
+    logical CPUs but grants a 16-CPU quota; spinning 256 OpenMP threads on that quota stalls for minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline_worker(args):
+    """The same train step on the host: module surface + oracle/ss2d_oracle.py (torch CPU ops + C/OpenMP scan).
+    Bounded sample: `cpu_batch` images x (1 warm-up + cpu_steps timed) steps.  Runs in its own process."""
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    torch.set_num_threads(cores)
+    from medical_image_classification_amd.train import build_model
+    from oracle import ss2d_oracle
+    torch.manual_seed(0)
+    net = build_model(num_classes=args.num_classes, variant=args.variant)
+    ss2d_oracle.install(net)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    lossf = nn.CrossEntropyLoss()
+    x = torch.randn(args.cpu_batch, 3, args.res, args.res)
+    y = torch.randint(0, args.num_classes, (args.cpu_batch,))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = lossf(net(x), y)
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()                                   # warm-up (allocator, oneDNN primitives)
+    print(f"[cpu_baseline] warm-up step {time.perf_counter() - t0:.1f} s on {cores} threads", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_batch * args.cpu_steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"MedMamba-{args.variant} fp32 full train step (fwd+bwd+Adam), bs={args.cpu_batch}, "
+                      f"{args.res}x{args.res}, 1 warm-up + {args.cpu_steps} timed step(s), {dt:.1f} s timed; "
+                      "scan = oracle/scan_oracle.c (OpenMP), other ops = torch CPU. The reference's own CPU path "
+                      "(Python-loop selective_scan_ref) measured 0.0046 images/s on 8 vCPU (BASELINE.md section 2)."}
+
+
+def cpu_baseline(args):
+    """Run the CPU leg in a fresh interpreter (no HIP runtime in it, OMP settings applied before any OpenMP
+    runtime starts) under a hard timeout, so it can never hang the bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch", str(args.cpu_batch),
+           "--cpu-steps", str(args.cpu_steps), "--res", str(args.res), "--num-classes", str(args.num_classes),
+           "--variant", args.variant]
+    env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=300, check=True)
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001 -- report, never hang or crash the GPU result
+        return {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port",
+                "sample": f"cpu baseline leg failed: {type(e).__name__}: {e}"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_worker(args)), flush=True)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise RuntimeError(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                               f"(WORLD_SIZE is {world})")
+    from medical_image_classification_amd import selective_scan_interface as ssi
+    from medical_image_classification_amd.ddp_train import setup_distributed, wrap_ddp
+    from medical_image_classification_amd.train import build_model, synthetic_batch, train_step
+
+    distributed, rank, world, local_rank = setup_distributed("nccl")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # MIOpen find mode for the conv branch (slow first use)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    torch.manual_seed(0)
+    net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
+    net.train()
+    model = wrap_ddp(net, distributed, local_rank)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    lossf = nn.CrossEntropyLoss()
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
+    ac = torch.bfloat16 if args.dtype == "bf16" else None
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"model on {device}, world {world}; warm-up {args.warmup} steps")
+    for i in range(args.warmup):
+        train_step(model, opt, lossf, images, labels, ac)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    barrier()
+    ssi.TIMER.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, opt, lossf, images, labels, ac)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ssi.TIMER.enabled = False
+    kern = ssi.TIMER.summary()
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    log(f"timed {args.steps} steps in {elapsed:.3f} s")
+
+    if rank == 0:
+        value = world * args.batch_size * args.steps / elapsed
+        dom = "scan_bwd" if kern.get("scan_bwd", {}).get("ms", 0) >= kern.get("scan_fwd", {}).get("ms", 0) else "scan_fwd"
+        k = kern[dom]
+        achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 4),
+                    "algorithmic_bytes_per_launch": k["bytes"] // k["launches"],
+                    "other": {n: {"GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                  "ms_per_step": round(v["ms"] / args.steps, 3)} for n, v in kern.items()}}
+        out = {"metric": f"images/sec MedMamba-{args.variant} 3x{args.res}x{args.res} bs={args.batch_size} train step",
+               "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype + "+f32scan" if args.dtype == "bf16" else "f32",
+               "data": "synthetic",
+               "config": {"workload": f"MedMamba-{args.variant} (depths/dims/d_state of BASELINE.json configs[1]) full "
+                                      f"training step fwd+bwd+Adam, {args.batch_size} x 3x{args.res}x{args.res} per GPU, "
+                                      f"{args.num_classes} classes, random-init weights",
+                          "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
+                          "loss": round(final_loss, 4)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu_baseline leg ...")
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

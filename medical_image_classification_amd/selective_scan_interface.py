@@ -21,6 +21,48 @@ from . import _lib
 from ._lib import MsScanBwdParams, MsScanParams
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the scan launches (bench.py's roofline leg).  Events are recorded on the
+    stream the kernel is launched on, immediately before and after the launch; nothing synchronises until
+    `summary()` is called after the timed region."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (kind, algorithmic_bytes, start_event, end_event)
+
+    def launch(self, kind, nbytes, device, fn):
+        if not self.enabled:
+            return fn()
+        s = torch.cuda.current_stream(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        rc = fn()
+        e1.record(s)
+        self.records.append((kind, nbytes, e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, nbytes, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "bytes": 0})
+            d["launches"] += 1; d["ms"] += e0.elapsed_time(e1); d["bytes"] += nbytes
+        self.records = []
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def algorithmic_bytes(batch, dim, L, N, G, backward):
+    """fp32, every operand of the operator touched once.
+    fwd: u, delta in, out (3*B*dim*L) + B, C (2*B*G*N*L) + A, D, bias (dim*(N+2))
+    bwd: u, delta, dout in, du, ddelta out (5*B*dim*L) + B, C in, dB, dC out (4*B*G*N*L)"""
+    if backward:
+        return 4 * (5 * batch * dim * L + 4 * batch * G * N * L)
+    return 4 * (3 * batch * dim * L + 2 * batch * G * N * L + dim * (N + 2))
+
+
 def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, delta_softplus):
     batch, dim, L = u.shape
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, L, A.shape[1], B.shape[1]
@@ -124,8 +166,9 @@ class SelectiveScanFn(torch.autograd.Function):
             P = MsScanParams()
             _fill_fwd(P, uf, df, Af, Bg, Cg, Dc, bc, out, x, delta_softplus)
             with torch.cuda.device(u.device):
-                _lib.check(lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(u.device)),
-                           "ms_selective_scan_fwd")
+                rc = TIMER.launch("scan_fwd", algorithmic_bytes(batch, dim, L, N, Bg.shape[1], False), u.device,
+                                  lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(u.device)))
+                _lib.check(rc, "ms_selective_scan_fwd")
         ctx.delta_softplus = bool(delta_softplus)
         ctx.has_z = z is not None
         ctx.in_dtype = in_dtype
@@ -173,8 +216,9 @@ class SelectiveScanFn(torch.autograd.Function):
             Q.dD = dD.data_ptr() if dD is not None else None
             Q.ddelta_bias = dbias.data_ptr() if dbias is not None else None
             with torch.cuda.device(uf.device):
-                _lib.check(lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(uf.device)),
-                           "ms_selective_scan_bwd")
+                rc = TIMER.launch("scan_bwd", algorithmic_bytes(batch, dim, L, N, G, True), uf.device,
+                                  lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(uf.device)))
+                _lib.check(rc, "ms_selective_scan_bwd")
 
         def back_to(grad, shape, dtype):   # undo _as_groups
             if len(shape) == 2:

@@ -1,0 +1,81 @@
+"""Single-device training loop -- counterpart of the reference's train.py (train.py:14-109): VSSM + Adam(1e-4) +
+CrossEntropyLoss, batch 32, best-accuracy state_dict checkpoint -- driven by SYNTHETIC data (the reference's
+ImageFolder dataset is not available offline; shapes and the hot loop are the same)."""
+import argparse
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from .medmamba import VSSM as medmamba
+
+
+def synthetic_batch(batch_size, num_classes, res=224, device="cuda", generator=None):
+    """`images, labels` with the shapes the reference's DataLoader yields (train.py:66-71)."""
+    images = torch.randn(batch_size, 3, res, res, device=device, generator=generator)
+    labels = torch.randint(0, num_classes, (batch_size,), device=device, generator=generator)
+    return images, labels
+
+
+def build_model(num_classes=8, variant="T", **kw):
+    if variant == "B":                      # BASELINE.json config 3
+        kw = dict(depths=[2, 2, 12, 2], dims=[128, 256, 512, 1024], **kw)
+    return medmamba(num_classes=num_classes, **kw)
+
+
+def train_step(net, optimizer, loss_function, images, labels, autocast_dtype=None):
+    """The hot loop body of train.py:73-77: zero_grad -> forward -> loss -> backward -> step."""
+    optimizer.zero_grad(set_to_none=True)
+    if autocast_dtype is not None:
+        with torch.autocast(device_type="cuda", dtype=autocast_dtype):
+            loss = loss_function(net(images), labels)
+    else:
+        loss = loss_function(net(images), labels)
+    loss.backward()
+    optimizer.step()
+    return loss
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--steps-per-epoch", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--num-classes", type=int, default=8)
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--save-path", default="./MedmambaNet.pth")
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise RuntimeError("train.py needs an MI355X: the SS2D kernels have no CPU fallback")
+    device = torch.device("cuda:0")
+    print(f"using {device} device.")
+    net = build_model(num_classes=args.num_classes).to(device)
+    loss_function = nn.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
+    gen = torch.Generator(device=device).manual_seed(0)
+    best_acc = 0.0
+    for epoch in range(args.epochs):
+        net.train()
+        running_loss, t0 = 0.0, time.time()
+        for step in range(args.steps_per_epoch):
+            images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
+            loss = train_step(net, optimizer, loss_function, images, labels, torch.bfloat16 if args.bf16 else None)
+            running_loss += loss.item()
+        dt = time.time() - t0
+        net.eval()
+        acc = 0
+        with torch.no_grad():
+            images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
+            acc = (net(images).argmax(dim=1) == labels).sum().item() / args.batch_size
+        print(f"[epoch {epoch + 1}] train_loss: {running_loss / args.steps_per_epoch:.3f}  val_accuracy: {acc:.3f}  "
+              f"{args.steps_per_epoch * args.batch_size / dt:.1f} images/s")
+        if acc >= best_acc:
+            best_acc = acc
+            torch.save(net.state_dict(), args.save_path)
+    print("Finished Training")
+
+
+if __name__ == "__main__":
+    main()
