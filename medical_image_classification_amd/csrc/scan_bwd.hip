@@ -9,221 +9,216 @@
 //   dA_n  += dh_l*delta'_l*(a_l*h_{l-1}) ;  dB += dh_l*delta'_l*u_l ;  dC += g_l*h_l ;  dD += g_l*u_l
 //   ddelta = ddl * softplus'(delta+bias),  softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
 //
-// Structure: lane = channel (scan_common.h); the NS waves of a workgroup own NPW states each.
-// Chunks of MS_SCAN_CHUNK positions are visited last->first; per chunk the forward states of the
-// wave's NPW states are RECOMPUTED from the saved state x[b,c-1] into registers (hist), then the
-// reverse pass runs over the same registers.  Per-position sums over n are combined across waves with
-// LDS float atomics.  The per-(l,n) dB/dC contributions of the 64 channels are summed by an
-// in-register butterfly reduce-scatter (~2 cross-lane adds per value instead of 6 for a plain
-// wave reduction), then one coalesced global atomic per (l,n) per 64-channel block.
-#include <type_traits>
+// One wave = 16 channels x all states, lane (sg, c) owns NPL states of channel c (scan_common.h).
+// Chunks of MS_SCAN_CHUNK positions are visited last->first (the next one is prefetched into registers).
+// Per chunk: (1) a forward sweep from the saved state x[b,c-1] stores h at the start of every 4-position
+// batch in LDS; (2) a reverse sweep recomputes (a, h) of one batch into a register window and runs the
+// adjoint recurrence backwards over it.  Sums over the state axis (du, ddelta) are permlane
+// reduce-scatters; the per-(l,n) dB/dC contributions are summed over the wave's 16 channels by a DPP
+// reduce-scatter into a per-chunk LDS tile, flushed with 128-byte-row global atomics.  No barriers.
 #include "scan_common.h"
 
 namespace ms {
 
-// Exchange-and-add step of the reduce-scatter at lane distance S: lanes with bit S clear keep `lo`,
-// the others keep `hi`; both add the partner's copy of what they keep.
-template <int S>
-__device__ __forceinline__ float xchg_add(float lo, float hi, int lane) {
-    const bool up = (lane & S) != 0;
-    const float keep = up ? hi : lo;
-    const float send = up ? lo : hi;
-    return keep + __shfl_xor(send, S, 64);
-}
-
-template <int K>   // level K exchanges at distance 32 >> K
-__device__ __forceinline__ float xchg_add_level(float lo, float hi, int lane) {
-    return xchg_add<(32 >> K)>(lo, hi, lane);
-}
-
-__device__ __forceinline__ int bitrev(int v, int bits) {
-    int r = 0;
-    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
-    return r;
-}
-
-// Streaming butterfly reduce-scatter of NPW values per position over the 64 lanes (channels).
-// Levels 0..LI-1 (distances 32, 16) fold the state index, the remaining levels fold position bits,
-// lowest bit first, so positions can be pushed one at a time in DESCENDING order and only one pending
-// value per level is live.  One flush covers kSpan consecutive positions; afterwards
-//   NPW == 4: lane j holds state (j >> 4),  position bitrev4(j & 15)           of the span
-//   NPW == 2: lane j holds state (j >> 5),  position bitrev5(j & 31)
-//   NPW == 1: lane j holds                  position bitrev5(j >> 1)           (both lanes of a pair)
-template <int NPW>
-struct ReduceScatter {
-    static constexpr int LI = NPW == 4 ? 2 : (NPW == 2 ? 1 : 0);     // state levels
-    static constexpr int LL = NPW == 4 ? 4 : 5;                      // position levels
-    static constexpr int kSpan = 1 << LL;
-    float pend[LL];
-
-    template <int K>
-    __device__ __forceinline__ void fold(int idx, float cur, int lane, float &result, bool &done) {
-        if constexpr (K == LL) {
-            if (NPW == 1) cur += __shfl_xor(cur, 1, 64);
-            result = cur; done = true;
+// Reduce NV (a power of two, zero-padded by the caller) values over the CW channel lanes of a wave
+// (lane bits 0 .. log2(CW)-1, all inside one DPP row).  Levels at distance CW/2 ... 1; while more than one
+// value is live a level halves the set (reduce-scatter), afterwards it is a plain butterfly add.
+// `owner_index(cbits, r)` tells which input index ended up in slot r of the lane with channel bits cbits.
+template <int NV, int CW>
+struct ChannelReduce {
+    static constexpr int kOut = NV >= CW ? NV / CW : 1;
+    template <int S, int CNT>
+    __device__ static __forceinline__ void level(float (&v)[NV], int lane) {
+        if constexpr (CNT > 1) {
+#pragma unroll
+            for (int i = 0; i < CNT / 2; ++i) v[i] = xchg_add<S>(v[i], v[i + CNT / 2], lane);
         } else {
-            if (idx & 1) { pend[K] = cur; }
-            else fold<K + 1>(idx >> 1, xchg_add_level<LI + K>(cur, pend[K], lane), lane, result, done);
+            constexpr int CTRL = S == 8 ? 0x128 : S == 4 ? 0x12C : S == 2 ? 0x4E : 0xB1;
+            constexpr int CTRL2 = S == 4 ? 0x124 : CTRL;
+            const float up = dpp_mov<CTRL>(v[0]), dn = dpp_mov<CTRL2>(v[0]);
+            v[0] += (lane & S) ? dn : up;
         }
     }
-    // l_in_span must be a compile-time constant after unrolling
-    __device__ __forceinline__ bool push(int l_in_span, const float (&v)[NPW], int lane, float &result) {
-        float cur;
-        if constexpr (NPW == 4) {
-            const float a = xchg_add_level<0>(v[0], v[2], lane);
-            const float b = xchg_add_level<0>(v[1], v[3], lane);
-            cur = xchg_add_level<1>(a, b, lane);
-        } else if constexpr (NPW == 2) {
-            cur = xchg_add_level<0>(v[0], v[1], lane);
+    __device__ static __forceinline__ void run(float (&v)[NV], int lane) {
+        if constexpr (CW == 16) {
+            level<8, NV>(v, lane);
+            level<4, (NV >= 2 ? NV / 2 : 1)>(v, lane);
+            level<2, (NV >= 4 ? NV / 4 : 1)>(v, lane);
+            level<1, (NV >= 8 ? NV / 8 : 1)>(v, lane);
         } else {
-            cur = v[0];
+            level<4, NV>(v, lane);
+            level<2, (NV >= 2 ? NV / 2 : 1)>(v, lane);
+            level<1, (NV >= 4 ? NV / 4 : 1)>(v, lane);
         }
-        bool done = false;
-        fold<0>(l_in_span, cur, lane, result, done);
-        return done;
+    }
+    __device__ static __forceinline__ int owner_index(int cbits, int r) {
+        int idx = r, cnt = NV;
+        constexpr int LV = CW == 16 ? 4 : 3;
+#pragma unroll
+        for (int k = 0; k < LV; ++k) {
+            const int bit = (cbits >> (LV - 1 - k)) & 1;
+            if (cnt > 1) { idx += bit * (cnt / 2); cnt /= 2; }
+        }
+        return idx;
+    }
+    // lanes that own distinct results (when NV < CW several lanes hold the same total)
+    __device__ static __forceinline__ bool is_owner(int cbits) {
+        if (NV >= CW) return true;
+        return (cbits & (CW / NV - 1)) == 0;        // the low channel bits only replicate
     }
 };
 
-template <int NPW, bool LCONTIG, bool BC_CONTIG>
-__global__ void __launch_bounds__(256, 2)
-scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int nblk) {
-    static_assert(kCL == 32, "chunk length is baked into the reduce-scatter spans");
-    using RS = ReduceScatter<NPW>;
+constexpr int next_pow2(int v) { int r = 1; while (r < v) r *= 2; return r; }
+
+template <int NPL, int CW, bool LCONTIG>
+__global__ void __launch_bounds__(64)
+scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
+    constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4, NV = next_pow2(4 * NPL);
+    using Tile = TileIO<LCONTIG, CW>;
+    using Rows = RowIO<NP>;
+    using CR = ChannelReduce<NV, CW>;
+    constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     const MsScanParams &p = q.f;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int lane = tid & 63;
-    const int wave = uniform(tid >> 6);
-    const int NS = nthreads >> 6;
+    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];
+    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
+    __shared__ __attribute__((aligned(16))) float sdB[NP * kRowPitch];   // this chunk's dB / dC of the wave's 16 channels
+    __shared__ __attribute__((aligned(16))) float sdC[NP * kRowPitch];
+    __shared__ float su[kTile];       // u tile      -> du tile
+    __shared__ float sdl[kTile];      // delta' tile
+    __shared__ float sg_[kTile];      // dout tile   -> ddelta tile
+    __shared__ float sck[NB * NPL * 64];   // h at the start of each 4-position batch
+    __shared__ float sbias[kCW];
+    const int lane = threadIdx.x;
+    const int c = lane % CW, sg = lane / CW;
 
+    const int N = p.dstate, L = p.seqlen;
     const int dpg = p.dim / p.n_groups;
-    int bid = blockIdx.x;
-    const int dblk = bid % nblk; bid /= nblk;
-    const int g = bid % p.n_groups;
-    const int b = bid / p.n_groups;
-    const int nvalid = min(64, dpg - dblk * 64);
-    const int d0 = g * dpg + dblk * 64;
-    const bool active = lane < nvalid;
-    const int d = d0 + (active ? lane : nvalid - 1);
-    const int L = p.seqlen;
+    // workgroup -> (batch, group, channel block).  Workgroups are dealt round-robin over the 8 XCDs, so the
+    // waves that share one (batch, group)'s B/C rows are given equal blockIdx % 8: they hit one XCD's L2
+    // instead of making all eight fetch the same rows (speed only, never correctness).
+    int pair, cb;
+    {
+        const int npairs = p.batch * p.n_groups, bid = blockIdx.x;
+        const int full = (npairs / 8) * 8 * ncb;            // pairs that form complete groups of 8
+        if (bid < full) { pair = (bid / (8 * ncb)) * 8 + bid % 8; cb = (bid / 8) % ncb; }
+        else            { pair = (npairs / 8) * 8 + (bid - full) / ncb; cb = (bid - full) % ncb; }
+    }
+    const int g = pair % p.n_groups;
+    const int b = pair / p.n_groups;
+    const int nvalid = min(kCW, dpg - cb * kCW);
+    const int d0 = g * dpg + cb * kCW;
+    const bool active = c < nvalid;
+    const int d = d0 + (active ? c : nvalid - 1);
 
-    float *su = smem;               // u tile      -> du tile
-    float *sdl = su + kTile;        // delta' tile
-    float *sg = sdl + kTile;        // dout tile   -> ddelta tile
-    float *sbias = sg + kTile;      // [64]
-    float *sdu = sbias + 64;        // [kCL][64] sum over states of du      (LDS atomics)
-    float *sdd = sdu + kCL * 64;    // [kCL][64] sum over states of ddelta'
-    float *sck = sdd + kCL * 64 + wave * (kCL / 4) * NPW * 64;   // per wave: h at the start of each 4-position batch
-
-    const int n0 = wave * NPW;
-    float An[NPW], A2[NPW], dhc[NPW], dAacc[NPW];
+    float An[NPL], A2[NPL], dhc[NPL], dAacc[NPL];
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        An[i] = p.A[d * p.A_d_stride + (n0 + i) * p.A_dstate_stride];
+    for (int i = 0; i < NPL; ++i) {
+        const int n = sg * NPL + i;
+        An[i] = n < N ? p.A[d * p.A_d_stride + n * p.A_dstate_stride] : 0.0f;
         A2[i] = An[i] * kLog2e;
         dhc[i] = 0.0f; dAacc[i] = 0.0f;
     }
-    const float Dv = (p.D != nullptr && wave == 0) ? p.D[d] : 0.0f;
+    const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;
+    const float fD = sg == 0 ? 1.0f : 0.0f;            // dD is accumulated once per channel, by group 0
     float dDacc = 0.0f, dbacc = 0.0f;
-    if (wave == 0) sbias[lane] = p.delta_bias ? p.delta_bias[d] : 0.0f;
-    __syncthreads();
+    if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, nvalid - 1)] : 0.0f;
 
     const float *ub = p.u + b * p.u_batch_stride + d0 * p.u_d_stride;
     const float *db = p.delta + b * p.delta_batch_stride + d0 * p.delta_d_stride;
     const float *gb = q.dout + b * q.dout_batch_stride + d0 * q.dout_d_stride;
     float *dub = q.du + b * q.du_batch_stride + d0 * q.du_d_stride;
     float *ddb = q.ddelta + b * q.ddelta_batch_stride + d0 * q.ddelta_d_stride;
-    const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride + n0 * p.B_dstate_stride;
-    const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride + n0 * p.C_dstate_stride;
-    const int64_t sBn = p.B_dstate_stride, sBl = p.B_l_stride, sCn = p.C_dstate_stride, sCl = p.C_l_stride;
+    const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
+    const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
+    float *dBb = q.dB + ((int64_t)b * p.n_groups + g) * N * L;
+    float *dCb = q.dC + ((int64_t)b * p.n_groups + g) * N * L;
     const bool softplus = p.delta_softplus != 0;
-    // (state, position-in-span) this lane owns after a reduce-scatter flush
-    int rs_i, rs_l; bool rs_writer = true;
-    if (NPW == 4)      { rs_i = lane >> 4; rs_l = bitrev(lane & 15, 4); }
-    else if (NPW == 2) { rs_i = lane >> 5; rs_l = bitrev(lane & 31, 5); }
-    else               { rs_i = 0; rs_l = bitrev(lane >> 1, 5); rs_writer = (lane & 1) == 0; }
-    float *dBl = q.dB + (((int64_t)b * p.n_groups + g) * p.dstate + n0 + rs_i) * L;
-    float *dCl = q.dC + (((int64_t)b * p.n_groups + g) * p.dstate + n0 + rs_i) * L;
 
-    auto chunk = [&](auto full_tag, const int c) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int l0 = c * kCL;
-        const int len = FULL ? kCL : L - l0;
-        load_tile<LCONTIG>(su, ub + l0 * p.u_l_stride, p.u_d_stride, p.u_l_stride, nvalid, len, tid, nthreads);
-        load_tile<LCONTIG>(sg, gb + l0 * q.dout_l_stride, q.dout_d_stride, q.dout_l_stride, nvalid, len, tid, nthreads);
-#pragma unroll 4
-        for (int idx = tid; idx < kCL * 64; idx += nthreads) {
-            int l, dl; tile_coord<LCONTIG>(idx, l, dl);
-            float v = 0.0f;
-            if (l < len && dl < nvalid) {
-                v = db[dl * p.delta_d_stride + (l0 + l) * p.delta_l_stride] + sbias[dl];
-                if (softplus) v = softplus_ref(v);
-            }
-            sdl[l * kPitch + dl] = v;
-            sdu[idx] = 0.0f; sdd[idx] = 0.0f;
+    const Tile tile(lane);
+    const Rows rows(lane);
+    const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
+    float ru[Tile::NE], rd[Tile::NE], rg[Tile::NE], rB[Rows::NE], rC[Rows::NE];
+    auto fetch = [&](int ch) {
+        const int l0 = ch * kCL, len = min(kCL, L - l0);
+        tile.fetch(ru, ub + l0 * p.u_l_stride, p.u_d_stride, p.u_l_stride, nvalid, len);
+        tile.fetch(rd, db + l0 * p.delta_l_stride, p.delta_d_stride, p.delta_l_stride, nvalid, len);
+        tile.fetch(rg, gb + l0 * q.dout_l_stride, q.dout_d_stride, q.dout_l_stride, nvalid, len);
+        rows.fetch(rB, Bb + l0 * p.B_l_stride, p.B_dstate_stride, p.B_l_stride, N, len);
+        rows.fetch(rC, Cb + l0 * p.C_l_stride, p.C_dstate_stride, p.C_l_stride, N, len);
+    };
+    fetch(n_chunks - 1);
+    wave_sync();                                           // sbias visible
+
+    for (int ch = n_chunks - 1; ch >= 0; --ch) {
+        const int l0 = ch * kCL, len = min(kCL, L - l0);
+        tile.put(su, ru);
+        tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
+        tile.put(sg_, rg);
+        rows.put(sB, rB);
+        rows.put(sC, rC);
+        float h[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int n = sg * NPL + i;
+            h[i] = (ch > 0 && n < N) ? p.x[(((int64_t)b * n_chunks + (ch - 1)) * N + n) * p.dim + d] : 0.0f;
         }
-        __syncthreads();
+        wave_sync();
+        if (ch > 0) fetch(ch - 1);                         // lands while this chunk is computed
 
-        RS rsB, rsC;
-        // ---- forward sweep: h at the start of every 4-position batch -> LDS (per-wave region) -------
-        {
-            float h[NPW];
-#pragma unroll
-            for (int i = 0; i < NPW; ++i)
-                h[i] = c > 0 ? p.x[(((int64_t)b * n_chunks + (c - 1)) * p.dstate + n0 + i) * p.dim + d] : 0.0f;
+        // ---- forward sweep: h at the start of every 4-position batch -> LDS ---------------------------
 #pragma unroll 1
-            for (int kb = 0; kb < kCL / 4; ++kb) {
-                const int lb = kb * 4;
-                float Bv[NPW][4];
+        for (int kb = 0; kb < NB; ++kb) {
+            const int lb = kb * 4;
+            float Bv[NPL][4];
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) {
-                    sck[(kb * NPW + i) * 64 + lane] = h[i];
-                    load_row<4, BC_CONTIG, FULL>(Bb + i * sBn, sBl, l0 + lb, L, Bv[i]);
-                }
+            for (int i = 0; i < NPL; ++i) {
+                sck[(kb * NPL + i) * 64 + lane] = h[i];
+                row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv[i]);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float dl_ = sdl[(lb + j) * kPitch + lane];
-                    const float du_ = dl_ * su[(lb + j) * kPitch + lane];
+            for (int j = 0; j < 4; ++j) {
+                const float dl_ = sdl[(lb + j) * kPitch + c];
+                const float du_ = dl_ * su[(lb + j) * kPitch + c];
 #pragma unroll
-                    for (int i = 0; i < NPW; ++i)
-                        h[i] = fmaf(exp2_fast(dl_ * A2[i]), h[i], du_ * Bv[i][j]);
-                }
+                for (int i = 0; i < NPL; ++i)
+                    h[i] = fmaf(exp2_fast(dl_ * A2[i]), h[i], du_ * Bv[i][j]);
             }
         }
         // ---- reverse sweep: per batch, recompute (a, h) into a 4-position register window, then run the
         //      adjoint recurrence backwards over the window --------------------------------------------
 #pragma unroll 1
-        for (int kb = kCL / 4 - 1; kb >= 0; --kb) {
+        for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            float Bv[NPW][4], Cv[NPW][4], hs[NPW];
+            float Bv[NPL][4], Cv[NPL][4], hs[NPL];
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                hs[i] = sck[(kb * NPW + i) * 64 + lane];
-                load_row<4, BC_CONTIG, FULL>(Bb + i * sBn, sBl, l0 + lb, L, Bv[i]);
-                load_row<4, BC_CONTIG, FULL>(Cb + i * sCn, sCl, l0 + lb, L, Cv[i]);
+            for (int i = 0; i < NPL; ++i) {
+                hs[i] = sck[(kb * NPL + i) * 64 + lane];
+                row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv[i]);
+                row4(sC + (sg * NPL + i) * kRowPitch, lb, Cv[i]);
             }
-            float dl_[4], uu[4], gg[4], av[4][NPW], hv[4][NPW];
+            float dl_[4], uu[4], gg[4], av[4][NPL], hv[4][NPL];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                dl_[j] = sdl[(lb + j) * kPitch + lane];
-                uu[j] = su[(lb + j) * kPitch + lane];
-                gg[j] = sg[(lb + j) * kPitch + lane];
+                dl_[j] = sdl[(lb + j) * kPitch + c];
+                uu[j] = su[(lb + j) * kPitch + c];
+                gg[j] = sg_[(lb + j) * kPitch + c];
                 const float du_ = dl_[j] * uu[j];
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) {
+                for (int i = 0; i < NPL; ++i) {
                     av[j][i] = exp2_fast(dl_[j] * A2[i]);
                     hv[j][i] = fmaf(av[j][i], j > 0 ? hv[j > 0 ? j - 1 : 0][i] : hs[i], du_ * Bv[i][j]);
                 }
             }
+            float duv[4], ddv[4], vB[NV], vC[NV];
+#pragma unroll
+            for (int r = 4 * NPL; r < NV; ++r) { vB[r] = 0.0f; vC[r] = 0.0f; }
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
-                const int l = lb + j;
                 const float du_ = dl_[j] * uu[j];
                 float du_l = Dv * gg[j], dd_l = 0.0f;
-                dDacc = fmaf(gg[j], uu[j], dDacc);
-                float vB[NPW], vC[NPW];
+                dDacc = fmaf(fD * gg[j], uu[j], dDacc);
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) {
+                for (int i = 0; i < NPL; ++i) {
                     const float hprev = j > 0 ? hv[j > 0 ? j - 1 : 0][i] : hs[i];
                     const float dhn = fmaf(Cv[i][j], gg[j], dhc[i]);
                     const float w = av[j][i] * hprev;
@@ -233,73 +228,84 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int nblk) {
                     const float qv = dhn * w;
                     dd_l = fmaf(qv, An[i], dd_l);
                     dAacc[i] = fmaf(qv, dl_[j], dAacc[i]);
-                    vB[i] = dhn * du_;
-                    vC[i] = gg[j] * hv[j][i];
+                    vB[j * NPL + i] = dhn * du_;
+                    vC[j * NPL + i] = gg[j] * hv[j][i];
                     dhc[i] = av[j][i] * dhn;
                 }
-                if (NS == 1) { sdu[l * 64 + lane] = du_l; sdd[l * 64 + lane] = dd_l; }
-                else { atomicAdd(&sdu[l * 64 + lane], du_l); atomicAdd(&sdd[l * 64 + lane], dd_l); }
-                float rB = 0.0f, rC = 0.0f;
-                const bool doneB = rsB.push(l & (RS::kSpan - 1), vB, lane, rB);
-                const bool doneC = rsC.push(l & (RS::kSpan - 1), vC, lane, rC);
-                if (doneB && doneC) {
-                    const int span0 = l & ~(RS::kSpan - 1);
-                    if (rs_writer && (FULL || span0 + rs_l < len)) {
-                        atomicAdd(dBl + l0 + span0 + rs_l, rB);
-                        atomicAdd(dCl + l0 + span0 + rs_l, rC);
+                duv[j] = du_l; ddv[j] = dd_l;
+            }
+            // sums over the state axis: group sg receives the totals of position lb + sg
+            const float du_t = sum_groups_scatter4<CW>(duv, lane);
+            float dd_t = sum_groups_scatter4<CW>(ddv, lane);
+            if (is_group_owner<CW>(lane)) {
+                const int lo = lb + group_slot<CW>(lane);
+                if (softplus) dd_t *= sigmoid_from_softplus(sdl[lo * kPitch + c]);
+                dbacc += dd_t;
+                su[lo * kPitch + c] = du_t;                // in place: this batch's u / dout are in registers
+                sg_[lo * kPitch + c] = dd_t;
+            }
+            // sums over the wave's 16 channels of the per-(position, state) dB / dC terms
+            CR::run(vB, lane);
+            CR::run(vC, lane);
+            if (CR::is_owner(c)) {
+#pragma unroll
+                for (int r = 0; r < CR::kOut; ++r) {
+                    const int idx = CR::owner_index(c, r);
+                    const int j = idx / NPL, i = idx % NPL;
+                    if (4 * NPL == NV || idx < 4 * NPL) {
+                        sdB[(sg * NPL + i) * kRowPitch + lb + j] = vB[r];
+                        sdC[(sg * NPL + i) * kRowPitch + lb + j] = vC[r];
                     }
                 }
             }
         }
-        __syncthreads();   // all waves are done with the u / dout tiles and with their LDS atomics
-
-        // ---- finish ddelta (softplus'), move the sums into the pitch-65 tiles, store -------------
-        for (int l = wave; l < kCL; l += NS) {
-            float dd = sdd[l * 64 + lane];
-            if (softplus) dd *= -expm1f(-sdl[l * kPitch + lane]);
-            dbacc += dd;
-            su[l * kPitch + lane] = sdu[l * 64 + lane];
-            sg[l * kPitch + lane] = dd;
+        wave_sync();
+        tile.store(su, dub + l0 * q.du_l_stride, q.du_d_stride, q.du_l_stride, nvalid, len);
+        tile.store(sg_, ddb + l0 * q.ddelta_l_stride, q.ddelta_d_stride, q.ddelta_l_stride, nvalid, len);
+        // flush the chunk's dB / dC tile: rows of 32 positions -> 128-byte atomic segments
+        {
+            const int l = lane % kCL, n0 = lane / kCL;
+            if (l < len) {
+#pragma unroll
+                for (int k = 0; k < NP / 2; ++k) {
+                    const int n = n0 + 2 * k;
+                    if (n < N) {
+                        atomicAdd(dBb + (int64_t)n * L + l0 + l, sdB[n * kRowPitch + l]);
+                        atomicAdd(dCb + (int64_t)n * L + l0 + l, sdC[n * kRowPitch + l]);
+                    }
+                }
+            }
         }
-        __syncthreads();
-        store_tile<LCONTIG>(su, dub + l0 * q.du_l_stride, q.du_d_stride, q.du_l_stride, nvalid, len, tid, nthreads);
-        store_tile<LCONTIG>(sg, ddb + l0 * q.ddelta_l_stride, q.ddelta_d_stride, q.ddelta_l_stride, nvalid, len, tid, nthreads);
-        __syncthreads();
-    };
-
-    {
-        int c = n_chunks - 1;
-        if (L % kCL != 0) { chunk(std::false_type{}, c); --c; }
-        for (; c >= 0; --c) chunk(std::true_type{}, c);
+        wave_sync();
     }
 
     if (active) {
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) atomicAdd(q.dA + (int64_t)d * p.dstate + n0 + i, dAacc[i]);
-        if (q.dD != nullptr && wave == 0) atomicAdd(q.dD + d, dDacc);
+        for (int i = 0; i < NPL; ++i) {
+            const int n = sg * NPL + i;
+            if (n < N) atomicAdd(q.dA + (int64_t)d * N + n, dAacc[i]);
+        }
+        if (q.dD != nullptr && sg == 0) atomicAdd(q.dD + d, dDacc);
         if (q.ddelta_bias != nullptr) atomicAdd(q.ddelta_bias + d, dbacc);
     }
 }
 
 int validate_scan(const MsScanParams &p);
+int pick_npl(int dstate, int sg);
+bool use_cw8(const MsScanParams &p, bool backward);
 
-template <int NPW>
-static int launch_bwd(const MsScanBwdParams &q, int ns, int n_chunks, hipStream_t stream) {
+template <int NPL, int CW>
+static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream) {
     const MsScanParams &p = q.f;
     const int dpg = p.dim / p.n_groups;
-    const int nblk = (dpg + 63) / 64;
-    const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * nblk));
-    const dim3 block(64 * ns);
-    const size_t smem = sizeof(float) * (3 * kTile + 64 + 2 * kCL * 64 + (size_t)ns * (kCL / 4) * NPW * 64);
+    const int ncb = (dpg + CW - 1) / CW;
+    const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncb));
     const bool lcontig = p.u_l_stride == 1 && p.delta_l_stride == 1 && q.dout_l_stride == 1 &&
                          q.du_l_stride == 1 && q.ddelta_l_stride == 1;
     const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && q.dout_d_stride == 1 &&
-                         q.du_d_stride == 1 && q.ddelta_d_stride == 1;
-    const bool bcc = p.B_l_stride == 1 && p.C_l_stride == 1;
-#define MS_LAUNCH(LC, BC) hipLaunchKernelGGL((scan_bwd_kernel<NPW, LC, BC>), grid, block, smem, stream, q, n_chunks, nblk)
-    if (lcontig || !dcontig) { if (bcc) MS_LAUNCH(true, true); else MS_LAUNCH(true, false); }
-    else                     { if (bcc) MS_LAUNCH(false, true); else MS_LAUNCH(false, false); }
-#undef MS_LAUNCH
+                         q.du_d_stride == 1 && q.ddelta_d_stride == 1 && !lcontig;
+    if (dcontig) hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, false>), grid, dim3(64), 0, stream, q, n_chunks, ncb);
+    else         hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, true>), grid, dim3(64), 0, stream, q, n_chunks, ncb);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
@@ -308,21 +314,26 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
     int rc = validate_scan(p);
     if (rc != MS_OK) return rc;
     if (!q.dout || !q.du || !q.ddelta || !q.dA || !q.dB || !q.dC) return MS_ERR_NULL;
+    const int64_t st[][2] = {{q.dout_d_stride, q.dout_l_stride}, {q.du_d_stride, q.du_l_stride},
+                             {q.ddelta_d_stride, q.ddelta_l_stride}};
+    for (auto &s : st)
+        if (s[0] < 0 || s[1] < 0 || (s[0] * 16 + s[1] * 32) * 4 >= ((int64_t)1 << 32)) return MS_ERR_STRIDE;
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
     if (n_chunks > 1 && !p.x) return MS_ERR_NULL;
-    // bwd keeps 256-thread workgroups (register budget): at most 4 waves split the state axis
-    int npw = 0, ns = 0;
-    const int cands[3] = {4, 2, 1};
-    for (int k = 0; k < 3 && !npw; ++k)
-        if (p.dstate % cands[k] == 0 && p.dstate / cands[k] <= 4) { npw = cands[k]; ns = p.dstate / cands[k]; }
-    if (!npw) return MS_ERR_DSTATE;
-    switch (npw) {
-        case 1: return launch_bwd<1>(q, ns, n_chunks, stream);
-        case 2: return launch_bwd<2>(q, ns, n_chunks, stream);
-        case 4: return launch_bwd<4>(q, ns, n_chunks, stream);
+    if (use_cw8(p, true)) {
+        switch (pick_npl(p.dstate, 8)) {
+            case 1: return launch_bwd<1, 8>(q, n_chunks, stream);
+            case 2: return launch_bwd<2, 8>(q, n_chunks, stream);
+        }
     }
-    return MS_ERR_DSTATE;
+    switch (pick_npl(p.dstate, 4)) {
+        case 1: return launch_bwd<1, 16>(q, n_chunks, stream);
+        case 2: return launch_bwd<2, 16>(q, n_chunks, stream);
+        case 3: return launch_bwd<3, 16>(q, n_chunks, stream);
+        case 4: return launch_bwd<4, 16>(q, n_chunks, stream);
+    }
+    return MS_ERR_DSTATE;       // backward is built for dstate <= 16
 }
 
 }  // namespace ms

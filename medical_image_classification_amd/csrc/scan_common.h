@@ -1,14 +1,17 @@
-// Shared device helpers for the gfx950 selective-scan kernels (wave64, lane = channel).
+// Shared device helpers for the gfx950 selective-scan kernels (wave64).
 //
-// Mapping used by every scan kernel in this directory (DESIGN.md "Kernel design"):
-//   * one workgroup = one block of 64 channels of one (batch, group); lane <-> channel, so the
-//     recurrence h_l = a_l*h_{l-1} + b_l runs sequentially IN REGISTERS along L with no cross-lane
-//     scan at all, and B[b,g,n,l] / C[b,g,n,l] are wave-uniform -> scalar (SMEM) loads, SGPR operands;
-//   * the workgroup's NS waves split the dstate axis (NPW states per wave); the per-position partial
-//     sums over n are combined through LDS;
-//   * activations are staged per chunk of MS_SCAN_CHUNK positions as an LDS tile [l][lane]
-//     (pitch 65 floats: conflict-free both for the coalesced global<->LDS copy of a (B,D,L) tensor
-//     and for the per-lane reads), which also serves channel-last tensors (pure stride change).
+// Work mapping (DESIGN.md "Kernel design"):
+//   * one WAVE = CW channels of one (batch, group) x all dstate states, CW = 16 or 8.  lane = sg*CW + c:
+//     c = lane % CW is the channel, sg = lane / CW one of SG = 64/CW state groups; a lane owns
+//     NPL = dstate/SG states of its channel.  (CW = 8 doubles the number of waves and halves the per-lane
+//     state: used when 16-channel waves would not fill the chip.)  The recurrence h_l = a_l*h_{l-1} + b_l runs sequentially IN REGISTERS
+//     along L -- no cross-lane scan; sums over the state axis are 2-step VALU exchanges
+//     (v_permlane32_swap / v_permlane16_swap), sums over the 16 channels are DPP row exchanges.
+//   * waves never talk to each other in the forward: every wave stages its own LDS tiles, so there is
+//     not a single s_barrier in the kernel and the hardware overlaps waves freely.
+//   * per chunk of MS_SCAN_CHUNK positions a wave stages u / delta' (/ dout) as [l][c] tiles (pitch 17)
+//     and the chunk's B/C rows as [n][l] (pitch 36: the 4 state groups hit disjoint bank quads), and
+//     prefetches the NEXT chunk into registers while computing the current one.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,68 +20,167 @@
 namespace ms {
 
 constexpr int kCL = MS_SCAN_CHUNK;   // positions per chunk / saved state
-constexpr int kPitch = 65;           // LDS tile pitch in floats
-constexpr int kTile = kCL * kPitch;  // floats per LDS tile
+constexpr int kRowPitch = kCL + 4;   // B/C row pitch (floats, 16-byte aligned rows)
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// softplus exactly as the reference: x <= 20 ? log1pf(expf(x)) : x
-// (selective_scan_fwd_kernel.cuh:153-156; F.softplus threshold 20 in selective_scan_interface.py:112-113)
-__device__ __forceinline__ float softplus_ref(float x) { return x <= 20.0f ? log1pf(expf(x)) : x; }
-
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Element <-> thread mapping of a [kCL positions][64 channels] tile so that consecutive threads touch
-// consecutive addresses of the tensor: along L for (B,D,L) tensors, along D for channel-last ones.
-template <bool LCONTIG>
-__device__ __forceinline__ void tile_coord(int idx, int &l, int &dl) {
-    if (LCONTIG) { l = idx % kCL; dl = idx / kCL; }
-    else         { dl = idx & 63; l = idx >> 6; }
+// softplus with the reference's definition, x <= 20 ? log1p(exp(x)) : x
+// (selective_scan_fwd_kernel.cuh:153-156; F.softplus threshold 20 in selective_scan_interface.py:112-113),
+// evaluated with the hardware exp2/log2 and Kahan's compensated log1p: log1p(e) = log(1+e) * e / ((1+e) - 1).
+// ~10 VALU ops instead of two libm calls (which cost as much per element as the whole 16-state recurrence);
+// relative error ~3e-7 over the whole range, including tiny e where log(1+e) alone would lose everything.
+__device__ __forceinline__ float softplus_ref(float x) {
+    const float e = exp2_fast(x * kLog2e);
+    const float u = 1.0f + e, dnm = u - 1.0f;
+    const float lg = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
+    const float r = dnm == 0.0f ? e : lg * (e * __builtin_amdgcn_rcpf(dnm));
+    return x <= 20.0f ? r : x;
 }
 
-// global -> LDS tile; rows past `nvalid` channels are zero (so idle lanes add nothing to lane reductions), positions past
-// `len` are zero-filled (the scan identity (a,b) = (1,0); selective_scan_fwd_kernel.cuh:218-222).
-template <bool LCONTIG>
-__device__ __forceinline__ void load_tile(float *s, const float *base, int64_t sd, int64_t sl,
-                                          int nvalid, int len, int tid, int nthreads) {
-#pragma unroll 4
-    for (int idx = tid; idx < kCL * 64; idx += nthreads) {
-        int l, dl; tile_coord<LCONTIG>(idx, l, dl);
-        float v = 0.0f;
-        if (l < len && dl < nvalid) v = base[dl * sd + l * sl];
-        s[l * kPitch + dl] = v;
+// softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x)), from the staged delta' (no second tile for the raw delta);
+// series below 2^-6 so the subtraction never cancels.
+__device__ __forceinline__ float sigmoid_from_softplus(float sp) {
+    const float direct = 1.0f - exp2_fast(-sp * kLog2e);
+    const float series = sp * (1.0f - sp * (0.5f - sp * (1.0f / 6.0f - sp * (1.0f / 24.0f))));
+    return sp < 0.015625f ? series : direct;
+}
+
+__device__ __forceinline__ float bits_f(unsigned v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ unsigned f_bits(float v) { return __builtin_bit_cast(unsigned, v); }
+
+// The compiler must not move LDS accesses of one lane across the point where another lane of the same
+// wave produced/consumes the data; the hardware executes a wave's LDS instructions in order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One [kCL positions][CW channels] activation tile moved by the 64 lanes of a wave:
+// global -> registers (asynchronous until first use), registers -> LDS, LDS -> global.
+// (B,D,L) tensors: lane owns position lane%32 of channels lane/32 + 2k (128-byte row segments);
+// channel-last tensors: lane owns channel lane%16 of positions lane/16 + 4k (64-byte segments).
+// Channels past `nvalid` and positions past `len` read as zero (the scan identity (a,b) = (1,0),
+// selective_scan_fwd_kernel.cuh:218-222; idle lanes then add nothing to lane sums).
+template <bool LCONTIG, int CW>
+struct TileIO {
+    static constexpr int kPitch = CW + 1;                        // LDS tile pitch (floats)
+    static constexpr int kTile = kCL * kPitch;
+    static constexpr int NE = kCL * CW / 64;                     // elements per lane
+    static constexpr int STEP = LCONTIG ? 64 / kCL : 64 / CW;    // channels (LCONTIG) or positions per k
+    int l0_, c0_;          // this lane's first (position, channel); one geometry serves every tensor
+    __device__ __forceinline__ explicit TileIO(int lane) {
+        if (LCONTIG) { l0_ = lane % kCL; c0_ = lane / kCL; } else { c0_ = lane % CW; l0_ = lane / CW; }
     }
-}
-
-template <bool LCONTIG>
-__device__ __forceinline__ void store_tile(const float *s, float *base, int64_t sd, int64_t sl,
-                                           int nvalid, int len, int tid, int nthreads) {
-#pragma unroll 4
-    for (int idx = tid; idx < kCL * 64; idx += nthreads) {
-        int l, dl; tile_coord<LCONTIG>(idx, l, dl);
-        if (l < len && dl < nvalid) base[dl * sd + l * sl] = s[l * kPitch + dl];
+    __device__ __forceinline__ int soff(int k) const { return l0_ * kPitch + c0_ + k * STEP * (LCONTIG ? 1 : kPitch); }
+    __device__ __forceinline__ uint32_t goff(int k, int64_t sd, int64_t sl) const {   // byte offset from the tile base
+        return (uint32_t)(c0_ * (int)sd + l0_ * (int)sl + k * STEP * (int)(LCONTIG ? sd : sl)) * 4u;
     }
-}
-
-// Read-only operands that are uniform across the wave (B, C) are read through the constant address
-// space: hipcc then issues them on the scalar unit (s_load_dword*, results in SGPRs, no VALU/VMEM slot).
-// Without this the in-kernel stores make the compiler fall back to 64-lane vector loads of one address.
-typedef const float __attribute__((address_space(4))) *cfloat_ptr;
-__device__ __forceinline__ cfloat_ptr as_const(const float *p) { return (cfloat_ptr)(uintptr_t)p; }
-
-// Wave-uniform loads of NL consecutive positions l = lstart .. lstart+NL-1 of one B/C row (scalar loads).
-// FULL: the positions are known to be inside the row -> straight-line, mergeable into s_load_dwordx4.
-// !FULL (last, partial chunk only): positions are clamped to L-1, so nothing outside the row is ever
-// touched; the clamped values only ever multiply the zero-filled u / delta' / dout of the padding.
-template <int NL, bool CONTIG, bool FULL>
-__device__ __forceinline__ void load_row(const float *__restrict__ row, int64_t sl, int lstart, int L, float (&v)[NL]) {
-    cfloat_ptr p = as_const(row);
+    __device__ __forceinline__ bool ok(int k, int nvalid, int len) const {
+        return LCONTIG ? (l0_ < len && c0_ + k * STEP < nvalid) : (l0_ + k * STEP < len && c0_ < nvalid);
+    }
+    // branch-free: out-of-range elements read the tile's first element (always valid) and are zeroed by a
+    // select, so the NE loads stay one straight-line batch instead of NE exec-masked blocks
+    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sd, int64_t sl, int nvalid, int len) const {
+        const char *b = reinterpret_cast<const char *>(base);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        const int l = FULL ? lstart + j : min(lstart + j, L - 1);
-        v[j] = CONTIG ? p[l] : p[l * sl];
+        for (int k = 0; k < NE; ++k) {
+            const bool v = ok(k, nvalid, len);
+            const float t = *reinterpret_cast<const float *>(b + (v ? goff(k, sd, sl) : 0u));
+            r[k] = v ? t : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) s[soff(k)] = r[k];
+    }
+    // delta tile: bias + softplus applied once per element on the way into LDS (sp_mask = all ones / zero:
+    // a bit-select instead of a branch per element)
+    __device__ __forceinline__ void put_delta(float *s, const float (&r)[NE], const float *sbias, unsigned sp_mask,
+                                              int nvalid, int len) const {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const float raw = r[k] + sbias[LCONTIG ? c0_ + k * STEP : c0_];
+            const float v = bits_f((f_bits(softplus_ref(raw)) & sp_mask) | (f_bits(raw) & ~sp_mask));
+            s[soff(k)] = ok(k, nvalid, len) ? v : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void store(const float *s, float *base, int64_t sd, int64_t sl, int nvalid, int len) const {
+        char *b = reinterpret_cast<char *>(base);
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (ok(k, nvalid, len)) *reinterpret_cast<float *>(b + goff(k, sd, sl)) = s[soff(k)];
+    }
+};
+
+// The chunk's B (or C) rows: NP = 4*NPL (padded) states x kCL positions, LDS layout [n][kRowPitch];
+// rows past the real dstate and positions past `len` are zero.  Lane owns position lane%32 of rows lane/32 + 2k.
+template <int NP>
+struct RowIO {
+    static constexpr int NE = NP / 2;
+    int l_, n_;
+    __device__ __forceinline__ explicit RowIO(int lane) { l_ = lane % kCL; n_ = lane / kCL; }
+    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sn, int64_t sl, int N, int len) const {
+        const char *b = reinterpret_cast<const char *>(base);
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const bool v = n_ + 2 * k < N && l_ < len;
+            const uint32_t off = (uint32_t)((n_ + 2 * k) * (int)sn + l_ * (int)sl) * 4u;
+            const float t = *reinterpret_cast<const float *>(b + (v ? off : 0u));
+            r[k] = v ? t : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) s[(n_ + 2 * k) * kRowPitch + l_] = r[k];
+    }
+};
+
+// 4 consecutive positions of one staged B/C row: one ds_read_b128 (4 distinct addresses per wave, one per
+// state group, 16 lanes each broadcast).
+__device__ __forceinline__ void row4(const float *srow, int lb, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(srow + lb);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+
+// ---- cross-lane exchange-and-add (pure VALU: v_permlane32/16_swap, DPP) ------------------------------
+// Lanes with bit S clear keep `lo`, the others keep `hi`; each adds its partner's (lane ^ S) copy of the
+// value it keeps.  Building block of the butterfly reduce-scatters.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return bits_f(__builtin_amdgcn_update_dpp(0u, f_bits(x), CTRL, 0xF, 0xF, true));
+}
+template <int S>
+__device__ __forceinline__ float xchg_add(float lo, float hi, int lane) {
+    if constexpr (S == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(f_bits(lo), f_bits(hi), false, false);
+        return bits_f(r[0]) + bits_f(r[1]);
+    } else if constexpr (S == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(f_bits(lo), f_bits(hi), false, false);
+        return bits_f(r[0]) + bits_f(r[1]);
+    } else {
+        // DPP row_ror:n: destination lane j reads source lane (j - n) mod 16 of its row.
+        // S=8: ror:8 both ways; S=4: ror:12 reads j+4, ror:4 reads j-4; S=2/1: quad_perm [2,3,0,1] / [1,0,3,2]
+        constexpr int UP = S == 8 ? 0x128 : S == 4 ? 0x12C : S == 2 ? 0x4E : 0xB1;
+        constexpr int DN = S == 8 ? 0x128 : S == 4 ? 0x124 : S == 2 ? 0x4E : 0xB1;
+        const float a = lo + dpp_mov<UP>(lo);     // valid where bit S is clear (partner = lane + S)
+        const float b = hi + dpp_mov<DN>(hi);     // valid where bit S is set   (partner = lane - S)
+        return (lane & S) ? b : a;
     }
 }
+
+// Sum over the SG = 64/CW state groups of 4 values, scattered: on return the lanes with
+// group_slot(lane) == j (and is_group_owner) hold the total of v[j].
+template <int CW>
+__device__ __forceinline__ float sum_groups_scatter4(const float (&v)[4], int lane) {
+    const float a = xchg_add<32>(v[0], v[2], lane);
+    const float b = xchg_add<32>(v[1], v[3], lane);
+    float r = xchg_add<16>(a, b, lane);
+    if constexpr (CW == 8) r += dpp_mov<0x128>(r);          // third group bit (lane bit 3): plain butterfly add
+    return r;
+}
+template <int CW> __device__ __forceinline__ int group_slot(int lane) { return lane >> 4; }          // = lane bits 5,4
+template <int CW> __device__ __forceinline__ bool is_group_owner(int lane) { return CW == 16 || (lane & 8) == 0; }
 
 }  // namespace ms

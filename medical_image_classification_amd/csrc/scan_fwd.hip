@@ -5,168 +5,171 @@
 //   a      = exp2(delta' * A[d,n] * log2e)     b = delta' * u * B[b,g,n,l]
 //   h_l    = a*h_{l-1} + b                     y_l = sum_n C[b,g,n,l]*h_l + D[d]*u_l
 //
-// Design (see scan_common.h): lane = channel, sequential recurrence in registers, B/C as scalar
-// operands, NS waves per workgroup split the state axis, per-chunk LDS tiles for u/delta/out.
-// Algorithmic traffic per (b,d,l): 12 B (u, delta in; out) + B/C shared by 64 channels + 16*4/32 B of
-// saved state; no operand is read twice from HBM.
-#include <type_traits>
+// One wave = 16 channels x all states (scan_common.h): lane (sg, c) runs NPL states of channel c
+// sequentially in registers; the sum over the state axis is a 2-step permlane reduce-scatter per 4
+// positions.  No barriers, no cross-wave traffic; 1 workgroup = 1 wave.
+// Algorithmic traffic per (b,d,l): 12 B (u, delta in; out) + B/C rows (L2-served, shared by the waves of a
+// group) + dstate*4/32 B of saved state; no activation is read twice from HBM.
 #include "scan_common.h"
 
 namespace ms {
 
-template <int NPW, bool LCONTIG, bool BC_CONTIG>
-__global__ void __launch_bounds__(1024)
-scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int nblk) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int lane = tid & 63;
-    const int wave = uniform(tid >> 6);
-    const int NS = nthreads >> 6;
+template <int NPL, int CW, bool LCONTIG>
+__global__ void __launch_bounds__(64)
+scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
+    constexpr int SG = 64 / CW, NP = SG * NPL;
+    using Tile = TileIO<LCONTIG, CW>;
+    constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
+    using Rows = RowIO<NP>;
+    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];
+    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
+    __shared__ float su[kTile];       // u tile, overwritten in place by the out tile
+    __shared__ float sdl[kTile];      // delta' tile
+    __shared__ float sbias[kCW];
+    const int lane = threadIdx.x;
+    const int c = lane % CW, sg = lane / CW;
 
+    const int N = p.dstate, L = p.seqlen;
     const int dpg = p.dim / p.n_groups;
-    int bid = blockIdx.x;
-    const int dblk = bid % nblk; bid /= nblk;
-    const int g = bid % p.n_groups;
-    const int b = bid / p.n_groups;
-    const int nvalid = min(64, dpg - dblk * 64);
-    const int d0 = g * dpg + dblk * 64;
-    const bool active = lane < nvalid;
-    const int d = d0 + (active ? lane : nvalid - 1);
+    // workgroup -> (batch, group, channel block).  Workgroups are dealt round-robin over the 8 XCDs, so the
+    // waves that share one (batch, group)'s B/C rows are given equal blockIdx % 8: they hit one XCD's L2
+    // instead of making all eight fetch the same rows (speed only, never correctness).
+    int pair, cb;
+    {
+        const int npairs = p.batch * p.n_groups, bid = blockIdx.x;
+        const int full = (npairs / 8) * 8 * ncb;            // pairs that form complete groups of 8
+        if (bid < full) { pair = (bid / (8 * ncb)) * 8 + bid % 8; cb = (bid / 8) % ncb; }
+        else            { pair = (npairs / 8) * 8 + (bid - full) / ncb; cb = (bid - full) % ncb; }
+    }
+    const int g = pair % p.n_groups;
+    const int b = pair / p.n_groups;
+    const int nvalid = min(kCW, dpg - cb * kCW);
+    const int d0 = g * dpg + cb * kCW;
+    const bool active = c < nvalid;
+    const int d = d0 + (active ? c : nvalid - 1);
 
-    float *su = smem;                 // u tile, later the out tile
-    float *sdl = su + kTile;          // delta' tile
-    float *sbias = sdl + kTile;       // [64]
-    float *sy = sbias + 64;           // [NS][kCL][64] partial y (NS > 1 only)
-
-    const int n0 = wave * NPW;
-    float A2[NPW], h[NPW];
+    float A2[NPL], h[NPL];
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        A2[i] = p.A[d * p.A_d_stride + (n0 + i) * p.A_dstate_stride] * kLog2e;
+    for (int i = 0; i < NPL; ++i) {
+        const int n = sg * NPL + i;
+        A2[i] = n < N ? p.A[d * p.A_d_stride + n * p.A_dstate_stride] * kLog2e : 0.0f;
         h[i] = 0.0f;
     }
-    const float Dv = (p.D != nullptr && wave == 0) ? p.D[d] : 0.0f;
-    if (wave == 0) sbias[lane] = p.delta_bias ? p.delta_bias[d] : 0.0f;
-    __syncthreads();
+    const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;   // the D*u term is added once, by group 0
+    if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, nvalid - 1)] : 0.0f;
 
     const float *ub = p.u + b * p.u_batch_stride + d0 * p.u_d_stride;
     const float *db = p.delta + b * p.delta_batch_stride + d0 * p.delta_d_stride;
     float *ob = p.out + b * p.out_batch_stride + d0 * p.out_d_stride;
-    const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride + n0 * p.B_dstate_stride;
-    const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride + n0 * p.C_dstate_stride;
+    const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
+    const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = p.delta_softplus != 0;
 
-    const int64_t sBn = p.B_dstate_stride, sBl = p.B_l_stride, sCn = p.C_dstate_stride, sCl = p.C_l_stride;
-    const int L = p.seqlen;
+    const Tile tile(lane);
+    const Rows rows(lane);
+    const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
+    float ru[Tile::NE], rd[Tile::NE], rB[Rows::NE], rC[Rows::NE];
+    auto fetch = [&](int ch) {
+        const int l0 = ch * kCL, len = min(kCL, L - l0);
+        tile.fetch(ru, ub + l0 * p.u_l_stride, p.u_d_stride, p.u_l_stride, nvalid, len);
+        tile.fetch(rd, db + l0 * p.delta_l_stride, p.delta_d_stride, p.delta_l_stride, nvalid, len);
+        rows.fetch(rB, Bb + l0 * p.B_l_stride, p.B_dstate_stride, p.B_l_stride, N, len);
+        rows.fetch(rC, Cb + l0 * p.C_l_stride, p.C_dstate_stride, p.C_l_stride, N, len);
+    };
+    fetch(0);
+    wave_sync();                                           // sbias visible
 
-    // one chunk of kCL positions; FULL = every position is inside the sequence (no tail handling at all)
-    auto chunk = [&](auto full_tag, const int c) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int l0 = c * kCL;
-        const int len = FULL ? kCL : L - l0;
-        load_tile<LCONTIG>(su, ub + l0 * p.u_l_stride, p.u_d_stride, p.u_l_stride, nvalid, len, tid, nthreads);
-        // delta tile with bias + softplus applied once per element
-#pragma unroll 4
-        for (int idx = tid; idx < kCL * 64; idx += nthreads) {
-            int l, dl; tile_coord<LCONTIG>(idx, l, dl);
-            float v = 0.0f;
-            if (l < len && dl < nvalid) {
-                v = db[dl * p.delta_d_stride + (l0 + l) * p.delta_l_stride] + sbias[dl];
-                if (softplus) v = softplus_ref(v);
-            }
-            sdl[l * kPitch + dl] = v;
-        }
-        __syncthreads();
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int l0 = ch * kCL, len = min(kCL, L - l0);
+        tile.put(su, ru);
+        tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
+        rows.put(sB, rB);
+        rows.put(sC, rC);
+        wave_sync();
+        if (ch + 1 < n_chunks) fetch(ch + 1);              // lands while this chunk is computed
 
-        constexpr int LB = 4;
 #pragma unroll 2
-        for (int lb = 0; lb < kCL; lb += LB) {
-            float dl_[LB], du_[LB], y[LB];
+        for (int lb = 0; lb < kCL; lb += 4) {
+            float dl_[4], du_[4], y[4];
 #pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                dl_[j] = sdl[(lb + j) * kPitch + lane];
-                const float uu = su[(lb + j) * kPitch + lane];
+            for (int j = 0; j < 4; ++j) {
+                dl_[j] = sdl[(lb + j) * kPitch + c];
+                const float uu = su[(lb + j) * kPitch + c];
                 du_[j] = dl_[j] * uu;
                 y[j] = Dv * uu;
             }
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                float Bv[LB], Cv[LB];
-                load_row<LB, BC_CONTIG, FULL>(Bb + i * sBn, sBl, l0 + lb, L, Bv);
-                load_row<LB, BC_CONTIG, FULL>(Cb + i * sCn, sCl, l0 + lb, L, Cv);
+            for (int i = 0; i < NPL; ++i) {
+                float Bv[4], Cv[4];
+                row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv);
+                row4(sC + (sg * NPL + i) * kRowPitch, lb, Cv);
 #pragma unroll
-                for (int j = 0; j < LB; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     const float a = exp2_fast(dl_[j] * A2[i]);
                     h[i] = fmaf(a, h[i], du_[j] * Bv[j]);
                     y[j] = fmaf(Cv[j], h[i], y[j]);
                 }
             }
-            if (NS == 1) {
-#pragma unroll
-                for (int j = 0; j < LB; ++j) su[(lb + j) * kPitch + lane] = y[j];   // in place: u_l is dead
-            } else {
-#pragma unroll
-                for (int j = 0; j < LB; ++j) sy[(wave * kCL + lb + j) * 64 + lane] = y[j];
-            }
+            // sum over the state groups; the owner lanes of slot j end up with the result of position lb + j
+            const float yt = sum_groups_scatter4<CW>(y, lane);
+            if (is_group_owner<CW>(lane)) su[(lb + group_slot<CW>(lane)) * kPitch + c] = yt;   // in place: u is in registers
         }
         if (p.x != nullptr && active) {
 #pragma unroll
-            for (int i = 0; i < NPW; ++i)
-                p.x[(((int64_t)b * n_chunks + c) * p.dstate + n0 + i) * p.dim + d] = h[i];
-        }
-        __syncthreads();
-        if (NS > 1) {
-            for (int l = wave; l < len; l += NS) {
-                float acc = sy[l * 64 + lane];
-                for (int w = 1; w < NS; ++w) acc += sy[(w * kCL + l) * 64 + lane];
-                su[l * kPitch + lane] = acc;
+            for (int i = 0; i < NPL; ++i) {
+                const int n = sg * NPL + i;
+                if (n < N) p.x[(((int64_t)b * n_chunks + ch) * N + n) * p.dim + d] = h[i];
             }
-            __syncthreads();
         }
-        store_tile<LCONTIG>(su, ob + l0 * p.out_l_stride, p.out_d_stride, p.out_l_stride, nvalid, len, tid, nthreads);
-        __syncthreads();
-    };
-
-    const int n_full = L / kCL;
-    for (int c = 0; c < n_full; ++c) chunk(std::true_type{}, c);
-    if (n_full < n_chunks) chunk(std::false_type{}, n_full);
-}
-
-// (NPW, NS) tiling of the state axis: NPW states per wave, NS = dstate / NPW waves per workgroup.
-static bool pick_tiling(int dstate, int max_ns, int &npw, int &ns) {
-    const int cands[5] = {4, 2, 1, 8, 16};
-    for (int k = 0; k < 5; ++k) {
-        const int c = cands[k];
-        if (dstate % c == 0 && dstate / c <= max_ns) { npw = c; ns = dstate / c; return true; }
+        wave_sync();
+        tile.store(su, ob + l0 * p.out_l_stride, p.out_d_stride, p.out_l_stride, nvalid, len);
+        wave_sync();
     }
-    return false;
 }
 
-template <int NPW>
-static int launch_fwd(const MsScanParams &p, int ns, int n_chunks, hipStream_t stream) {
+// states per lane for a given dstate and number of state groups; 0 = unsupported
+int pick_npl(int dstate, int sg) {
+    const int need = (dstate + sg - 1) / sg;
+    const int cands[6] = {1, 2, 3, 4, 8, 16};
+    for (int k = 0; k < 6; ++k) if (cands[k] >= need) return cands[k];
+    return 0;
+}
+
+// 8-channel waves (8 state groups) when 16-channel waves would leave the chip under-filled.
+bool use_cw8(const MsScanParams &p, bool backward) {
     const int dpg = p.dim / p.n_groups;
-    const int nblk = (dpg + 63) / 64;
-    const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * nblk));
-    const dim3 block(64 * ns);
-    const size_t smem = sizeof(float) * (2 * kTile + 64 + (ns > 1 ? (size_t)ns * kCL * 64 : 0));
-    const bool lcontig = p.u_l_stride == 1 && p.delta_l_stride == 1 && p.out_l_stride == 1;
-    const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && p.out_d_stride == 1;
-    const bool bcc = p.B_l_stride == 1 && p.C_l_stride == 1;
-    if (!lcontig && !dcontig && p.seqlen > 1 && dpg > 1) {
-        // arbitrary strides still work (tile_coord only chooses the coalescing direction)
-    }
-#define MS_LAUNCH(LC, BC) hipLaunchKernelGGL((scan_fwd_kernel<NPW, LC, BC>), grid, block, smem, stream, p, n_chunks, nblk)
-    if (lcontig || !dcontig) { if (bcc) MS_LAUNCH(true, true); else MS_LAUNCH(true, false); }
-    else                     { if (bcc) MS_LAUNCH(false, true); else MS_LAUNCH(false, false); }
-#undef MS_LAUNCH
+    const int64_t waves16 = (int64_t)p.batch * p.n_groups * ((dpg + 15) / 16);
+    // the backward keeps twice the per-lane state: 8-channel waves are the only way to 2 waves/SIMD there
+    return p.dstate >= 8 && p.dstate <= 16 && (backward || waves16 < 8192);
+}
+
+template <int NPL, int CW>
+static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
+    const int dpg = p.dim / p.n_groups;
+    const int ncb = (dpg + CW - 1) / CW;
+    const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncb));
+    // channel-last tensors (unit channel stride) are tiled along D, everything else along L
+    const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && p.out_d_stride == 1 &&
+                         !(p.u_l_stride == 1 && p.delta_l_stride == 1 && p.out_l_stride == 1);
+    if (dcontig) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, false>), grid, dim3(64), 0, stream, p, n_chunks, ncb);
+    else         hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, true>), grid, dim3(64), 0, stream, p, n_chunks, ncb);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
+
+static bool fits_u32(int64_t a) { return a >= 0 && a < ((int64_t)1 << 32); }
 
 int validate_scan(const MsScanParams &p) {
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return MS_ERR_NULL;
     if (p.batch < 0 || p.dim <= 0 || p.seqlen < 0 || p.dstate <= 0 || p.n_groups <= 0) return MS_ERR_SHAPE;
     if (p.dim % p.n_groups != 0) return MS_ERR_SHAPE;
     if (p.dstate > 256) return MS_ERR_DSTATE;
+    // tile-relative byte offsets are kept in 32 bits: one 32x16 tile / one set of B/C rows must span < 4 GiB
+    const int64_t strides[][2] = {{p.u_d_stride, p.u_l_stride}, {p.delta_d_stride, p.delta_l_stride},
+                                  {p.B_dstate_stride * 4, p.B_l_stride}, {p.C_dstate_stride * 4, p.C_l_stride}};
+    for (auto &s : strides) {
+        if (s[0] < 0 || s[1] < 0) return MS_ERR_STRIDE;
+        if (!fits_u32((s[0] * 16 + s[1] * 32) * 4)) return MS_ERR_STRIDE;
+    }
     return MS_OK;
 }
 
@@ -174,18 +177,24 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
     int rc = validate_scan(p);
     if (rc != MS_OK) return rc;
     if (!p.out) return MS_ERR_NULL;
+    if (p.out_d_stride < 0 || p.out_l_stride < 0 || !fits_u32((p.out_d_stride * 16 + p.out_l_stride * 32) * 4)) return MS_ERR_STRIDE;
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
-    int npw, ns;
-    if (!pick_tiling(p.dstate, 16, npw, ns)) return MS_ERR_DSTATE;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
-    switch (npw) {
-        case 1: return launch_fwd<1>(p, ns, n_chunks, stream);
-        case 2: return launch_fwd<2>(p, ns, n_chunks, stream);
-        case 4: return launch_fwd<4>(p, ns, n_chunks, stream);
-        case 8: return launch_fwd<8>(p, ns, n_chunks, stream);
-        case 16: return launch_fwd<16>(p, ns, n_chunks, stream);
+    if (use_cw8(p, false)) {
+        switch (pick_npl(p.dstate, 8)) {
+            case 1: return launch_fwd<1, 8>(p, n_chunks, stream);
+            case 2: return launch_fwd<2, 8>(p, n_chunks, stream);
+        }
     }
-    return MS_ERR_DSTATE;
+    switch (pick_npl(p.dstate, 4)) {
+        case 1: return launch_fwd<1, 16>(p, n_chunks, stream);
+        case 2: return launch_fwd<2, 16>(p, n_chunks, stream);
+        case 3: return launch_fwd<3, 16>(p, n_chunks, stream);
+        case 4: return launch_fwd<4, 16>(p, n_chunks, stream);
+        case 8: return launch_fwd<8, 16>(p, n_chunks, stream);
+        case 16: return launch_fwd<16, 16>(p, n_chunks, stream);
+    }
+    return MS_ERR_DSTATE;       // dstate > 64: not tiled by this build
 }
 
 }  // namespace ms
