@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 1
+#define MEDSCAN_ABI_VERSION 2
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -43,10 +43,13 @@ typedef enum MsStatus {
 
 /*
  * Launch parameters of the selective scan; the field set of the reference's SSMParamsBase
- * (selective_scan.h:26-69) with int64 element strides, an explicit sequence stride for every
- * activation (so (B,D,L) and channel-last (B,L,D) tensors are both first-class) and no z/complex.
+ * (selective_scan.h:26-69) with int64 element strides, an explicit sequence stride and group stride for
+ * every activation (so (B,D,L) and channel-last (B,L,D) tensors are both first-class) and no z/complex.
  *
- *   u, delta, out : logical shape (batch, dim, seqlen)
+ *   u, delta, out : logical shape (batch, dim, seqlen); channel d = g*(dim/n_groups) + dl of group g lives at
+ *                   base + b*batch_stride + g*group_stride + dl*d_stride + pos*l_stride
+ *                   (reference layout (B,D,L): group_stride = (dim/n_groups)*d_stride; a group_stride of 0 lets
+ *                   every group read the SAME tensor -- the 4 scan directions of SS2D over one feature map)
  *   A             : (dim, dstate)                         fp32, real
  *   B, C          : (batch, n_groups, dstate, seqlen)     channel d uses group d / (dim / n_groups)
  *   D, delta_bias : (dim) contiguous, may be NULL
@@ -56,13 +59,20 @@ typedef enum MsStatus {
  *                   (reference: x (batch,dim,n_chunks,2*dstate), selective_scan.cpp:313; the layout is
  *                   private to the extension there too, selective_scan_interface.py:46 only reads the
  *                   last state, which here is x[:, n_chunks-1].)
+ *   map_h, map_w  : 0, 0 = plain sequences (pos = l).  H, W > 0 (H*W == seqlen, n_groups % 4 == 0) = SS2D mode:
+ *                   every tensor is indexed by the PIXEL p = h*W + w and group g scans the pixels in the order of
+ *                   direction g % 4 of SS2D.forward_corev0 (MedMamba.py:393-395):
+ *                     0: p = l      1: p = (l % H)*W + l / H      2: p = L-1-l      3: p = map1(L-1-l)
+ *                   i.e. the cross-scan is folded into the kernel's addressing and the outputs come back in pixel
+ *                   order, so the cross-merge (MedMamba.py:420-424,476) is a plain sum over the 4 groups.
  */
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;
     int32_t delta_softplus;                 /* bool */
-    int64_t u_batch_stride, u_d_stride, u_l_stride;
-    int64_t delta_batch_stride, delta_d_stride, delta_l_stride;
-    int64_t out_batch_stride, out_d_stride, out_l_stride;
+    int32_t map_h, map_w;
+    int64_t u_batch_stride, u_group_stride, u_d_stride, u_l_stride;
+    int64_t delta_batch_stride, delta_group_stride, delta_d_stride, delta_l_stride;
+    int64_t out_batch_stride, out_group_stride, out_d_stride, out_l_stride;
     int64_t A_d_stride, A_dstate_stride;
     int64_t B_batch_stride, B_group_stride, B_dstate_stride, B_l_stride;
     int64_t C_batch_stride, C_group_stride, C_dstate_stride, C_l_stride;
@@ -73,16 +83,18 @@ typedef struct MsScanParams {
 
 /*
  * Backward; field set of SSMParamsBwd (selective_scan.h:71-101).
- *   dout, du, ddelta : (batch, dim, seqlen) with their own strides
- *   dA (dim,dstate) contiguous; dB, dC (batch,n_groups,dstate,seqlen) contiguous fp32;
+ *   dout, du, ddelta : (batch, dim, seqlen) with their own batch/group/d/l strides (same addressing as u)
+ *   dA (dim,dstate) contiguous; dB, dC (batch,n_groups,dstate,seqlen) with their own strides, fp32;
  *   dD, ddelta_bias (dim) or NULL.  dA/dB/dC/dD/ddelta_bias are ACCUMULATED INTO (atomics).
  *   x is required when seqlen > MS_SCAN_CHUNK.
  */
 typedef struct MsScanBwdParams {
     MsScanParams f;                          /* forward operands; f.out is unused, f.x is read */
-    int64_t dout_batch_stride, dout_d_stride, dout_l_stride;
-    int64_t du_batch_stride, du_d_stride, du_l_stride;
-    int64_t ddelta_batch_stride, ddelta_d_stride, ddelta_l_stride;
+    int64_t dout_batch_stride, dout_group_stride, dout_d_stride, dout_l_stride;
+    int64_t du_batch_stride, du_group_stride, du_d_stride, du_l_stride;
+    int64_t ddelta_batch_stride, ddelta_group_stride, ddelta_d_stride, ddelta_l_stride;
+    int64_t dB_batch_stride, dB_group_stride, dB_dstate_stride, dB_l_stride;
+    int64_t dC_batch_stride, dC_group_stride, dC_dstate_stride, dC_l_stride;
     const float *dout;
     float *du, *ddelta, *dA, *dB, *dC, *dD, *ddelta_bias;
 } MsScanBwdParams;

@@ -20,11 +20,11 @@ class MsScanParams(ctypes.Structure):
     """Mirror of `MsScanParams` (include/medscan.h); field set of the reference's SSMParamsBase
     (selective_scan.h:26-69)."""
     _fields_ = (
-        [(n, c_i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "delta_softplus")]
+        [(n, c_i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "delta_softplus", "map_h", "map_w")]
         + [(n, c_i64) for n in (
-            "u_batch_stride", "u_d_stride", "u_l_stride",
-            "delta_batch_stride", "delta_d_stride", "delta_l_stride",
-            "out_batch_stride", "out_d_stride", "out_l_stride",
+            "u_batch_stride", "u_group_stride", "u_d_stride", "u_l_stride",
+            "delta_batch_stride", "delta_group_stride", "delta_d_stride", "delta_l_stride",
+            "out_batch_stride", "out_group_stride", "out_d_stride", "out_l_stride",
             "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_dstate_stride", "B_l_stride",
             "C_batch_stride", "C_group_stride", "C_dstate_stride", "C_l_stride")]
@@ -37,9 +37,11 @@ class MsScanBwdParams(ctypes.Structure):
     _fields_ = (
         [("f", MsScanParams)]
         + [(n, c_i64) for n in (
-            "dout_batch_stride", "dout_d_stride", "dout_l_stride",
-            "du_batch_stride", "du_d_stride", "du_l_stride",
-            "ddelta_batch_stride", "ddelta_d_stride", "ddelta_l_stride")]
+            "dout_batch_stride", "dout_group_stride", "dout_d_stride", "dout_l_stride",
+            "du_batch_stride", "du_group_stride", "du_d_stride", "du_l_stride",
+            "ddelta_batch_stride", "ddelta_group_stride", "ddelta_d_stride", "ddelta_l_stride",
+            "dB_batch_stride", "dB_group_stride", "dB_dstate_stride", "dB_l_stride",
+            "dC_batch_stride", "dC_group_stride", "dC_dstate_stride", "dC_l_stride")]
         + [(n, c_vp) for n in ("dout", "du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias")]
     )
 
@@ -88,8 +90,8 @@ def lib():
     h.ms_status_string.argtypes = [ctypes.c_int]
     for name in EXPORTS[:-1]:
         getattr(h, name).restype = ctypes.c_int
-    if h.ms_abi_version() != 1:
-        raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != 1 (stale build?)")
+    if h.ms_abi_version() != 2:
+        raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != 2 (stale build?)")
     _lib = h
     return h
 

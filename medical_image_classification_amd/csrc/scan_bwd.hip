@@ -70,12 +70,12 @@ struct ChannelReduce {
 
 constexpr int next_pow2(int v) { int r = 1; while (r < v) r *= 2; return r; }
 
-template <int NPL, int CW, bool LCONTIG>
+template <int NPL, int CW, int MODE>
 __global__ void __launch_bounds__(64)
 scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4, NV = next_pow2(4 * NPL);
-    using Tile = TileIO<LCONTIG, CW>;
-    using Rows = RowIO<NP>;
+    using Tile = TileIO<MODE, CW>;
+    using Rows = RowIO<MODE, NP>;
     using CR = ChannelReduce<NV, CW>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     const MsScanParams &p = q.f;
@@ -123,15 +123,19 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float dDacc = 0.0f, dbacc = 0.0f;
     if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, nvalid - 1)] : 0.0f;
 
-    const float *ub = p.u + b * p.u_batch_stride + d0 * p.u_d_stride;
-    const float *db = p.delta + b * p.delta_batch_stride + d0 * p.delta_d_stride;
-    const float *gb = q.dout + b * q.dout_batch_stride + d0 * q.dout_d_stride;
-    float *dub = q.du + b * q.du_batch_stride + d0 * q.du_d_stride;
-    float *ddb = q.ddelta + b * q.ddelta_batch_stride + d0 * q.ddelta_d_stride;
+    const int c0w = cb * kCW;                                   // first channel of this wave inside its group
+    const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0w * p.u_d_stride;
+    const float *db = p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0w * p.delta_d_stride;
+    const float *gb = q.dout + b * q.dout_batch_stride + g * q.dout_group_stride + c0w * q.dout_d_stride;
+    float *dub = q.du + b * q.du_batch_stride + g * q.du_group_stride + c0w * q.du_d_stride;
+    float *ddb = q.ddelta + b * q.ddelta_batch_stride + g * q.ddelta_group_stride + c0w * q.ddelta_d_stride;
+    PosMap pm;
+    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.H = p.map_h; pm.W = p.map_w; pm.L = L;
+    pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
-    float *dBb = q.dB + ((int64_t)b * p.n_groups + g) * N * L;
-    float *dCb = q.dC + ((int64_t)b * p.n_groups + g) * N * L;
+    float *dBb = q.dB + b * q.dB_batch_stride + g * q.dB_group_stride;
+    float *dCb = q.dC + b * q.dC_batch_stride + g * q.dC_group_stride;
     const bool softplus = p.delta_softplus != 0;
 
     const Tile tile(lane);
@@ -140,11 +144,11 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float ru[Tile::NE], rd[Tile::NE], rg[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        tile.fetch(ru, ub + l0 * p.u_l_stride, p.u_d_stride, p.u_l_stride, nvalid, len);
-        tile.fetch(rd, db + l0 * p.delta_l_stride, p.delta_d_stride, p.delta_l_stride, nvalid, len);
-        tile.fetch(rg, gb + l0 * q.dout_l_stride, q.dout_d_stride, q.dout_l_stride, nvalid, len);
-        rows.fetch(rB, Bb + l0 * p.B_l_stride, p.B_dstate_stride, p.B_l_stride, N, len);
-        rows.fetch(rC, Cb + l0 * p.C_l_stride, p.C_dstate_stride, p.C_l_stride, N, len);
+        tile.fetch(ru, ub, p.u_d_stride, p.u_l_stride, l0, pm, nvalid, len);
+        tile.fetch(rd, db, p.delta_d_stride, p.delta_l_stride, l0, pm, nvalid, len);
+        tile.fetch(rg, gb, q.dout_d_stride, q.dout_l_stride, l0, pm, nvalid, len);
+        rows.fetch(rB, Bb, p.B_dstate_stride, p.B_l_stride, l0, pm, N, len);
+        rows.fetch(rC, Cb, p.C_dstate_stride, p.C_l_stride, l0, pm, N, len);
     };
     fetch(n_chunks - 1);
     wave_sync();                                           // sbias visible
@@ -260,22 +264,11 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             }
         }
         wave_sync();
-        tile.store(su, dub + l0 * q.du_l_stride, q.du_d_stride, q.du_l_stride, nvalid, len);
-        tile.store(sg_, ddb + l0 * q.ddelta_l_stride, q.ddelta_d_stride, q.ddelta_l_stride, nvalid, len);
-        // flush the chunk's dB / dC tile: rows of 32 positions -> 128-byte atomic segments
-        {
-            const int l = lane % kCL, n0 = lane / kCL;
-            if (l < len) {
-#pragma unroll
-                for (int k = 0; k < NP / 2; ++k) {
-                    const int n = n0 + 2 * k;
-                    if (n < N) {
-                        atomicAdd(dBb + (int64_t)n * L + l0 + l, sdB[n * kRowPitch + l]);
-                        atomicAdd(dCb + (int64_t)n * L + l0 + l, sdC[n * kRowPitch + l]);
-                    }
-                }
-            }
-        }
+        tile.store(su, dub, q.du_d_stride, q.du_l_stride, l0, pm, nvalid, len);
+        tile.store(sg_, ddb, q.ddelta_d_stride, q.ddelta_l_stride, l0, pm, nvalid, len);
+        // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
+        rows.flush_add(sdB, dBb, q.dB_dstate_stride, q.dB_l_stride, l0, pm, N, len);
+        rows.flush_add(sdC, dCb, q.dC_dstate_stride, q.dC_l_stride, l0, pm, N, len);
         wave_sync();
     }
 
@@ -293,6 +286,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 int validate_scan(const MsScanParams &p);
 int pick_npl(int dstate, int sg);
 bool use_cw8(const MsScanParams &p, bool backward);
+int pick_mode(bool l_contig, bool d_contig, int map_h);
+bool act_strides_ok(int64_t sd, int64_t sl, int seqlen);
 
 template <int NPL, int CW>
 static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream) {
@@ -303,9 +298,12 @@ static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream
     const bool lcontig = p.u_l_stride == 1 && p.delta_l_stride == 1 && q.dout_l_stride == 1 &&
                          q.du_l_stride == 1 && q.ddelta_l_stride == 1;
     const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && q.dout_d_stride == 1 &&
-                         q.du_d_stride == 1 && q.ddelta_d_stride == 1 && !lcontig;
-    if (dcontig) hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, false>), grid, dim3(64), 0, stream, q, n_chunks, ncb);
-    else         hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, true>), grid, dim3(64), 0, stream, q, n_chunks, ncb);
+                         q.du_d_stride == 1 && q.ddelta_d_stride == 1;
+    switch (pick_mode(lcontig, dcontig, p.map_h)) {
+        case kModeSS2D: hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64), 0, stream, q, n_chunks, ncb); break;
+        case kModeCL:   hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64), 0, stream, q, n_chunks, ncb); break;
+        default:        hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64), 0, stream, q, n_chunks, ncb); break;
+    }
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
@@ -314,10 +312,12 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
     int rc = validate_scan(p);
     if (rc != MS_OK) return rc;
     if (!q.dout || !q.du || !q.ddelta || !q.dA || !q.dB || !q.dC) return MS_ERR_NULL;
-    const int64_t st[][2] = {{q.dout_d_stride, q.dout_l_stride}, {q.du_d_stride, q.du_l_stride},
-                             {q.ddelta_d_stride, q.ddelta_l_stride}};
-    for (auto &s : st)
-        if (s[0] < 0 || s[1] < 0 || (s[0] * 16 + s[1] * 32) * 4 >= ((int64_t)1 << 32)) return MS_ERR_STRIDE;
+    if (!act_strides_ok(q.dout_d_stride, q.dout_l_stride, p.seqlen) || !act_strides_ok(q.du_d_stride, q.du_l_stride, p.seqlen) ||
+        !act_strides_ok(q.ddelta_d_stride, q.ddelta_l_stride, p.seqlen) ||
+        !act_strides_ok(q.dB_dstate_stride * 4, q.dB_l_stride, p.seqlen) || !act_strides_ok(q.dC_dstate_stride * 4, q.dC_l_stride, p.seqlen))
+        return MS_ERR_STRIDE;
+    if (p.map_h > 0 && (q.dout_d_stride != 1 || q.du_d_stride != 1 || q.ddelta_d_stride != 1 ||
+                        q.dB_dstate_stride != 1 || q.dC_dstate_stride != 1)) return MS_ERR_STRIDE;
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
     if (n_chunks > 1 && !p.x) return MS_ERR_NULL;

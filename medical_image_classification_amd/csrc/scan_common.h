@@ -57,14 +57,38 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sequence index -> memory position.  mode < 0: identity (plain sequences).  mode 0..3: the pixel visited at
+// step l by direction `mode` of SS2D's cross-scan over an H x W map (MedMamba.py:393-395):
+//   0: l    1: (l % H)*W + l / H    2: L-1-l    3: map1(L-1-l)
+struct PosMap {
+    int mode, H, W, L;
+    float invH;
+    __device__ __forceinline__ int operator()(int l) const {
+        if (mode < 0) return l;
+        int t = (mode & 2) ? L - 1 - l : l;
+        if (mode & 1) {
+            const int w = (int)(((float)t + 0.5f) * invH);      // exact for t < 2^22
+            t = (t - w * H) * W + w;
+        }
+        return t;
+    }
+};
+
+// kernel addressing modes
+constexpr int kModeBDL = 0;      // activations contiguous along L (reference (B,D,L) layout); B/C rows contiguous along L
+constexpr int kModeCL = 1;       // channel-last activations, B/C rows contiguous along L
+constexpr int kModeSS2D = 2;     // channel-last activations indexed by pixel through PosMap, B/C rows contiguous along n
+
 // One [kCL positions][CW channels] activation tile moved by the 64 lanes of a wave:
 // global -> registers (asynchronous until first use), registers -> LDS, LDS -> global.
 // (B,D,L) tensors: lane owns position lane%32 of channels lane/32 + 2k (128-byte row segments);
-// channel-last tensors: lane owns channel lane%16 of positions lane/16 + 4k (64-byte segments).
+// channel-last tensors: lane owns channel lane%CW of positions lane/CW + (64/CW)k.
 // Channels past `nvalid` and positions past `len` read as zero (the scan identity (a,b) = (1,0),
 // selective_scan_fwd_kernel.cuh:218-222; idle lanes then add nothing to lane sums).
-template <bool LCONTIG, int CW>
+// `base` points at (batch, group, first channel of the wave), position 0; `lbase` is the chunk's first position.
+template <int MODE, int CW>
 struct TileIO {
+    static constexpr bool LCONTIG = MODE == kModeBDL;
     static constexpr int kPitch = CW + 1;                        // LDS tile pitch (floats)
     static constexpr int kTile = kCL * kPitch;
     static constexpr int NE = kCL * CW / 64;                     // elements per lane
@@ -74,22 +98,31 @@ struct TileIO {
         if (LCONTIG) { l0_ = lane % kCL; c0_ = lane / kCL; } else { c0_ = lane % CW; l0_ = lane / CW; }
     }
     __device__ __forceinline__ int soff(int k) const { return l0_ * kPitch + c0_ + k * STEP * (LCONTIG ? 1 : kPitch); }
-    __device__ __forceinline__ uint32_t goff(int k, int64_t sd, int64_t sl) const {   // byte offset from the tile base
-        return (uint32_t)(c0_ * (int)sd + l0_ * (int)sl + k * STEP * (int)(LCONTIG ? sd : sl)) * 4u;
+    __device__ __forceinline__ int lk(int k) const { return LCONTIG ? l0_ : l0_ + k * STEP; }
+    __device__ __forceinline__ int ck(int k) const { return LCONTIG ? c0_ + k * STEP : c0_; }
+    __device__ __forceinline__ uint32_t goff(int k, int64_t sd, int64_t sl, int lbase, const PosMap &pm) const {
+        const int pos = MODE == kModeSS2D ? pm(lbase + lk(k)) : lbase + lk(k);
+        return (uint32_t)(ck(k) * (int)sd + pos * (int)sl) * 4u;
     }
-    __device__ __forceinline__ bool ok(int k, int nvalid, int len) const {
-        return LCONTIG ? (l0_ < len && c0_ + k * STEP < nvalid) : (l0_ + k * STEP < len && c0_ < nvalid);
-    }
+    __device__ __forceinline__ bool ok(int k, int nvalid, int len) const { return lk(k) < len && ck(k) < nvalid; }
     // branch-free: out-of-range elements read the tile's first element (always valid) and are zeroed by a
     // select, so the NE loads stay one straight-line batch instead of NE exec-masked blocks
-    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sd, int64_t sl, int nvalid, int len) const {
+    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sd, int64_t sl, int lbase,
+                                          const PosMap &pm, int nvalid, int len) const {
         const char *b = reinterpret_cast<const char *>(base);
+        const uint32_t safe = first_valid(sd, sl, lbase, pm);
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const bool v = ok(k, nvalid, len);
-            const float t = *reinterpret_cast<const float *>(b + (v ? goff(k, sd, sl) : 0u));
+            const uint32_t off = goff(k, sd, sl, lbase, pm);
+            const float t = *reinterpret_cast<const float *>(b + (v ? off : safe));
             r[k] = v ? t : 0.0f;
         }
+    }
+    // byte offset of an element that is always inside the tensor: (first position of the chunk, channel 0)
+    __device__ __forceinline__ uint32_t first_valid(int64_t sd, int64_t sl, int lbase, const PosMap &pm) const {
+        const int pos = MODE == kModeSS2D ? pm(lbase) : lbase;
+        return (uint32_t)(pos * (int)sl) * 4u;
     }
     __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
 #pragma unroll
@@ -101,39 +134,59 @@ struct TileIO {
                                               int nvalid, int len) const {
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const float raw = r[k] + sbias[LCONTIG ? c0_ + k * STEP : c0_];
+            const float raw = r[k] + sbias[ck(k)];
             const float v = bits_f((f_bits(softplus_ref(raw)) & sp_mask) | (f_bits(raw) & ~sp_mask));
             s[soff(k)] = ok(k, nvalid, len) ? v : 0.0f;
         }
     }
-    __device__ __forceinline__ void store(const float *s, float *base, int64_t sd, int64_t sl, int nvalid, int len) const {
+    __device__ __forceinline__ void store(const float *s, float *base, int64_t sd, int64_t sl, int lbase,
+                                          const PosMap &pm, int nvalid, int len) const {
         char *b = reinterpret_cast<char *>(base);
 #pragma unroll
         for (int k = 0; k < NE; ++k)
-            if (ok(k, nvalid, len)) *reinterpret_cast<float *>(b + goff(k, sd, sl)) = s[soff(k)];
+            if (ok(k, nvalid, len)) *reinterpret_cast<float *>(b + goff(k, sd, sl, lbase, pm)) = s[soff(k)];
     }
 };
 
-// The chunk's B (or C) rows: NP = 4*NPL (padded) states x kCL positions, LDS layout [n][kRowPitch];
-// rows past the real dstate and positions past `len` are zero.  Lane owns position lane%32 of rows lane/32 + 2k.
-template <int NP>
+// The chunk's B (or C) rows: NP (padded) states x kCL positions, LDS layout [n][kRowPitch]; rows past the real
+// dstate and positions past `len` are zero.  Rows contiguous along L: lane owns position lane%32 of rows
+// lane/32 + 2k (128-byte segments).  SS2D mode (rows contiguous along n, one projection row per pixel): lane owns
+// element idx = lane + 64k, n = idx % NP, l = idx / NP (NP*4-byte segments).
+template <int MODE, int NP>
 struct RowIO {
+    static constexpr bool NCONTIG = MODE == kModeSS2D;
     static constexpr int NE = NP / 2;
-    int l_, n_;
-    __device__ __forceinline__ explicit RowIO(int lane) { l_ = lane % kCL; n_ = lane / kCL; }
-    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sn, int64_t sl, int N, int len) const {
+    int lane_;
+    __device__ __forceinline__ explicit RowIO(int lane) : lane_(lane) {}
+    __device__ __forceinline__ int nk(int k) const { return NCONTIG ? (lane_ + 64 * k) % NP : lane_ / kCL + 2 * k; }
+    __device__ __forceinline__ int lk(int k) const { return NCONTIG ? (lane_ + 64 * k) / NP : lane_ % kCL; }
+    __device__ __forceinline__ uint32_t goff(int k, int64_t sn, int64_t sl, int lbase, const PosMap &pm) const {
+        const int pos = NCONTIG ? pm(lbase + lk(k)) : lbase + lk(k);
+        return (uint32_t)(nk(k) * (int)sn + pos * (int)sl) * 4u;
+    }
+    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sn, int64_t sl, int lbase,
+                                          const PosMap &pm, int N, int len) const {
         const char *b = reinterpret_cast<const char *>(base);
+        const uint32_t safe = (uint32_t)((NCONTIG ? pm(lbase) : lbase) * (int)sl) * 4u;     // (state 0, first position)
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const bool v = n_ + 2 * k < N && l_ < len;
-            const uint32_t off = (uint32_t)((n_ + 2 * k) * (int)sn + l_ * (int)sl) * 4u;
-            const float t = *reinterpret_cast<const float *>(b + (v ? off : 0u));
+            const bool v = nk(k) < N && lk(k) < len;
+            const float t = *reinterpret_cast<const float *>(b + (v ? goff(k, sn, sl, lbase, pm) : safe));
             r[k] = v ? t : 0.0f;
         }
     }
     __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) s[(n_ + 2 * k) * kRowPitch + l_] = r[k];
+        for (int k = 0; k < NE; ++k) s[nk(k) * kRowPitch + lk(k)] = r[k];
+    }
+    // accumulate a staged [n][l] tile into global memory (dB / dC of the backward)
+    __device__ __forceinline__ void flush_add(const float *s, float *base, int64_t sn, int64_t sl, int lbase,
+                                              const PosMap &pm, int N, int len) const {
+        char *b = reinterpret_cast<char *>(base);
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (nk(k) < N && lk(k) < len)
+                atomicAdd(reinterpret_cast<float *>(b + goff(k, sn, sl, lbase, pm)), s[nk(k) * kRowPitch + lk(k)]);
     }
 };
 

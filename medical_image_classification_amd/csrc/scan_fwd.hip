@@ -14,13 +14,13 @@
 
 namespace ms {
 
-template <int NPL, int CW, bool LCONTIG>
+template <int NPL, int CW, int MODE>
 __global__ void __launch_bounds__(64)
 scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL;
-    using Tile = TileIO<LCONTIG, CW>;
+    using Tile = TileIO<MODE, CW>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
-    using Rows = RowIO<NP>;
+    using Rows = RowIO<MODE, NP>;
     __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];
     __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
     __shared__ float su[kTile];       // u tile, overwritten in place by the out tile
@@ -58,9 +58,13 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;   // the D*u term is added once, by group 0
     if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, nvalid - 1)] : 0.0f;
 
-    const float *ub = p.u + b * p.u_batch_stride + d0 * p.u_d_stride;
-    const float *db = p.delta + b * p.delta_batch_stride + d0 * p.delta_d_stride;
-    float *ob = p.out + b * p.out_batch_stride + d0 * p.out_d_stride;
+    const int c0w = cb * kCW;                                   // first channel of this wave inside its group
+    const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0w * p.u_d_stride;
+    const float *db = p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0w * p.delta_d_stride;
+    float *ob = p.out + b * p.out_batch_stride + g * p.out_group_stride + c0w * p.out_d_stride;
+    PosMap pm;
+    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.H = p.map_h; pm.W = p.map_w; pm.L = L;
+    pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = p.delta_softplus != 0;
@@ -71,10 +75,10 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     float ru[Tile::NE], rd[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        tile.fetch(ru, ub + l0 * p.u_l_stride, p.u_d_stride, p.u_l_stride, nvalid, len);
-        tile.fetch(rd, db + l0 * p.delta_l_stride, p.delta_d_stride, p.delta_l_stride, nvalid, len);
-        rows.fetch(rB, Bb + l0 * p.B_l_stride, p.B_dstate_stride, p.B_l_stride, N, len);
-        rows.fetch(rC, Cb + l0 * p.C_l_stride, p.C_dstate_stride, p.C_l_stride, N, len);
+        tile.fetch(ru, ub, p.u_d_stride, p.u_l_stride, l0, pm, nvalid, len);
+        tile.fetch(rd, db, p.delta_d_stride, p.delta_l_stride, l0, pm, nvalid, len);
+        rows.fetch(rB, Bb, p.B_dstate_stride, p.B_l_stride, l0, pm, N, len);
+        rows.fetch(rC, Cb, p.C_dstate_stride, p.C_l_stride, l0, pm, N, len);
     };
     fetch(0);
     wave_sync();                                           // sbias visible
@@ -122,7 +126,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
             }
         }
         wave_sync();
-        tile.store(su, ob + l0 * p.out_l_stride, p.out_d_stride, p.out_l_stride, nvalid, len);
+        tile.store(su, ob, p.out_d_stride, p.out_l_stride, l0, pm, nvalid, len);
         wave_sync();
     }
 }
@@ -140,7 +144,13 @@ bool use_cw8(const MsScanParams &p, bool backward) {
     const int dpg = p.dim / p.n_groups;
     const int64_t waves16 = (int64_t)p.batch * p.n_groups * ((dpg + 15) / 16);
     // the backward keeps twice the per-lane state: 8-channel waves are the only way to 2 waves/SIMD there
-    return p.dstate >= 8 && p.dstate <= 16 && (backward || waves16 < 8192);
+    return p.dstate >= 8 && p.dstate <= 16 && (backward || waves16 < 2048);
+}
+
+// addressing mode from the strides (speed choice for plain sequences; SS2D mode when a map is given)
+int pick_mode(bool l_contig, bool d_contig, int map_h) {
+    if (map_h > 0) return kModeSS2D;
+    return (d_contig && !l_contig) ? kModeCL : kModeBDL;
 }
 
 template <int NPL, int CW>
@@ -148,28 +158,38 @@ static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
     const int dpg = p.dim / p.n_groups;
     const int ncb = (dpg + CW - 1) / CW;
     const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncb));
-    // channel-last tensors (unit channel stride) are tiled along D, everything else along L
-    const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && p.out_d_stride == 1 &&
-                         !(p.u_l_stride == 1 && p.delta_l_stride == 1 && p.out_l_stride == 1);
-    if (dcontig) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, false>), grid, dim3(64), 0, stream, p, n_chunks, ncb);
-    else         hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, true>), grid, dim3(64), 0, stream, p, n_chunks, ncb);
+    const bool lcontig = p.u_l_stride == 1 && p.delta_l_stride == 1 && p.out_l_stride == 1;
+    const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && p.out_d_stride == 1;
+    switch (pick_mode(lcontig, dcontig, p.map_h)) {
+        case kModeSS2D: hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64), 0, stream, p, n_chunks, ncb); break;
+        case kModeCL:   hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL>), grid, dim3(64), 0, stream, p, n_chunks, ncb); break;
+        default:        hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64), 0, stream, p, n_chunks, ncb); break;
+    }
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
 static bool fits_u32(int64_t a) { return a >= 0 && a < ((int64_t)1 << 32); }
+
+// an activation tensor is addressed with 32-bit byte offsets relative to its (batch, group, first channel) base
+bool act_strides_ok(int64_t sd, int64_t sl, int seqlen) {
+    if (sd < 0 || sl < 0) return false;
+    return fits_u32((sd * 16 + sl * (int64_t)(seqlen > 0 ? seqlen : 1)) * 4);
+}
 
 int validate_scan(const MsScanParams &p) {
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return MS_ERR_NULL;
     if (p.batch < 0 || p.dim <= 0 || p.seqlen < 0 || p.dstate <= 0 || p.n_groups <= 0) return MS_ERR_SHAPE;
     if (p.dim % p.n_groups != 0) return MS_ERR_SHAPE;
     if (p.dstate > 256) return MS_ERR_DSTATE;
-    // tile-relative byte offsets are kept in 32 bits: one 32x16 tile / one set of B/C rows must span < 4 GiB
-    const int64_t strides[][2] = {{p.u_d_stride, p.u_l_stride}, {p.delta_d_stride, p.delta_l_stride},
-                                  {p.B_dstate_stride * 4, p.B_l_stride}, {p.C_dstate_stride * 4, p.C_l_stride}};
-    for (auto &s : strides) {
-        if (s[0] < 0 || s[1] < 0) return MS_ERR_STRIDE;
-        if (!fits_u32((s[0] * 16 + s[1] * 32) * 4)) return MS_ERR_STRIDE;
+    if (p.map_h < 0 || p.map_w < 0 || (p.map_h > 0) != (p.map_w > 0)) return MS_ERR_SHAPE;
+    if (p.map_h > 0) {
+        if ((int64_t)p.map_h * p.map_w != p.seqlen || p.n_groups % 4 != 0 || p.seqlen >= (1 << 22)) return MS_ERR_SHAPE;
+        // SS2D mode needs channel-last activations and projection rows that are contiguous along the state axis
+        if (p.u_d_stride != 1 || p.delta_d_stride != 1 || p.B_dstate_stride != 1 || p.C_dstate_stride != 1) return MS_ERR_STRIDE;
     }
+    if (!act_strides_ok(p.u_d_stride, p.u_l_stride, p.seqlen) || !act_strides_ok(p.delta_d_stride, p.delta_l_stride, p.seqlen) ||
+        !act_strides_ok(p.B_dstate_stride * 4, p.B_l_stride, p.seqlen) || !act_strides_ok(p.C_dstate_stride * 4, p.C_l_stride, p.seqlen))
+        return MS_ERR_STRIDE;
     return MS_OK;
 }
 
@@ -177,7 +197,8 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
     int rc = validate_scan(p);
     if (rc != MS_OK) return rc;
     if (!p.out) return MS_ERR_NULL;
-    if (p.out_d_stride < 0 || p.out_l_stride < 0 || !fits_u32((p.out_d_stride * 16 + p.out_l_stride * 32) * 4)) return MS_ERR_STRIDE;
+    if (!act_strides_ok(p.out_d_stride, p.out_l_stride, p.seqlen)) return MS_ERR_STRIDE;
+    if (p.map_h > 0 && p.out_d_stride != 1) return MS_ERR_STRIDE;
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
     if (use_cw8(p, false)) {

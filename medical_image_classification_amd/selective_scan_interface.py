@@ -63,14 +63,23 @@ def algorithmic_bytes(batch, dim, L, N, G, backward):
     return 4 * (3 * batch * dim * L + 2 * batch * G * N * L + dim * (N + 2))
 
 
+def _act_strides(t, dpg):
+    """(batch, group, d, l) element strides of a (batch, dim, L) activation in the reference layout: group g
+    starts dpg channels after group g-1."""
+    sb, sd, sl = t.stride()
+    return sb, dpg * sd, sd, sl
+
+
 def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, delta_softplus):
     batch, dim, L = u.shape
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, L, A.shape[1], B.shape[1]
     P.delta_softplus = int(bool(delta_softplus))
-    P.u_batch_stride, P.u_d_stride, P.u_l_stride = u.stride()
-    P.delta_batch_stride, P.delta_d_stride, P.delta_l_stride = delta.stride()
+    P.map_h = P.map_w = 0
+    dpg = dim // B.shape[1]
+    P.u_batch_stride, P.u_group_stride, P.u_d_stride, P.u_l_stride = _act_strides(u, dpg)
+    P.delta_batch_stride, P.delta_group_stride, P.delta_d_stride, P.delta_l_stride = _act_strides(delta, dpg)
     if out is not None:
-        P.out_batch_stride, P.out_d_stride, P.out_l_stride = out.stride()
+        P.out_batch_stride, P.out_group_stride, P.out_d_stride, P.out_l_stride = _act_strides(out, dpg)
     P.A_d_stride, P.A_dstate_stride = A.stride()
     P.B_batch_stride, P.B_group_stride, P.B_dstate_stride, P.B_l_stride = B.stride()
     P.C_batch_stride, P.C_group_stride, P.C_dstate_stride, P.C_l_stride = C.stride()
@@ -208,9 +217,12 @@ class SelectiveScanFn(torch.autograd.Function):
         if batch > 0 and L > 0:
             Q = MsScanBwdParams()
             _fill_fwd(Q.f, uf, df, Af, Bg, Cg, Dc, bc, None, x, ctx.delta_softplus)
-            Q.dout_batch_stride, Q.dout_d_stride, Q.dout_l_stride = g.stride()
-            Q.du_batch_stride, Q.du_d_stride, Q.du_l_stride = du.stride()
-            Q.ddelta_batch_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = ddelta.stride()
+            dpg = dim // G
+            Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = _act_strides(g, dpg)
+            Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = _act_strides(du, dpg)
+            Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = _act_strides(ddelta, dpg)
+            Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = dB.stride()
+            Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = dC.stride()
             Q.dout, Q.du, Q.ddelta = g.data_ptr(), du.data_ptr(), ddelta.data_ptr()
             Q.dA, Q.dB, Q.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
             Q.dD = dD.data_ptr() if dD is not None else None
