@@ -126,6 +126,17 @@ int ms_dwconv3x3_silu_fwd(const float *x, const float *w, const float *bias, flo
 int ms_dwconv3x3_silu_bwd(const float *x, const float *w, const float *bias, const float *dy,
                           float *dx, float *dw, float *dbias, int batch, int C, int H, int W, void *stream);
 
+/*
+ * The same op on CHANNEL-LAST tensors (the layout in_proj produces; removes MedMamba.py:472's permute+copy):
+ *   x : (batch, H, W, *) fp32 or bf16 (x_is_bf16), pixel stride `x_pixel_stride` elements, first C channels used
+ *       (so the x half of xz = in_proj(x) is read in place);  y, dy, dx : (batch, H, W, C) contiguous fp32.
+ */
+int ms_dwconv3x3_silu_nhwc_fwd(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
+                               int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream);
+int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
+                               float *dx, float *scratch /* (batch,H,W,C) fp32 work buffer */, float *dw, float *dbias,
+                               int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream);
+
 int ms_abi_version(void);
 const char *ms_status_string(int status);
 

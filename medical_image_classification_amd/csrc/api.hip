@@ -12,6 +12,11 @@ int dwconv_fwd_dispatch(const float *x, const float *w, const float *bias, float
                         int batch, int C, int H, int W, hipStream_t s);
 int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const float *dy, float *dx,
                         float *dw, float *dbias, int batch, int C, int H, int W, hipStream_t s);
+int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
+                             int batch, int C, int H, int W, int64_t xps, hipStream_t s);
+int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
+                             float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
+                             int64_t xps, hipStream_t s);
 }  // namespace ms
 
 extern "C" {
@@ -44,6 +49,18 @@ int ms_dwconv3x3_silu_fwd(const float *x, const float *w, const float *bias, flo
 int ms_dwconv3x3_silu_bwd(const float *x, const float *w, const float *bias, const float *dy,
                           float *dx, float *dw, float *dbias, int batch, int C, int H, int W, void *stream) {
     return ms::dwconv_bwd_dispatch(x, w, bias, dy, dx, dw, dbias, batch, C, H, W, (hipStream_t)stream);
+}
+
+int ms_dwconv3x3_silu_nhwc_fwd(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
+                               int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream) {
+    return ms::dwconv_nhwc_fwd_dispatch(x, x_is_bf16, w, bias, y, batch, C, H, W, x_pixel_stride, (hipStream_t)stream);
+}
+
+int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
+                               float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
+                               int64_t x_pixel_stride, void *stream) {
+    return ms::dwconv_nhwc_bwd_dispatch(x, x_is_bf16, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W,
+                                        x_pixel_stride, (hipStream_t)stream);
 }
 
 int ms_abi_version(void) { return MEDSCAN_ABI_VERSION; }

@@ -1,0 +1,202 @@
+// Depthwise 3x3 conv (pad 1) + bias + SiLU on CHANNEL-LAST tensors for gfx950 -- the layout in_proj produces, so
+// the reference's `x.permute(0,3,1,2).contiguous()` before the conv (MedMamba.py:472) and the transpose back after
+// the scan (:477) disappear.
+//   x : (B, H, W, *) with pixel stride `xps` elements (reads the first C channels of each pixel, so the `x` half of
+//       in_proj's output xz is consumed in place);  y : (B, H, W, C) contiguous fp32.
+// One wave = 64 channels x one image row; lanes are channels (256-byte coalesced rows), the 3x3 window slides along W
+// in registers: 3 loads + 9 FMAs per output, every input row is fetched by 3 waves (L2 hits).
+//   bwd: two streaming passes -- (1) dpre = dy * silu'(pre) with pre recomputed, dw[c,k] / dbias[c] accumulated per lane over
+//        the row (one atomic per (row, channel)); (2) dx = conv^T(dpre).  dpre lives in a caller-provided scratch tensor.
+#include <hip/hip_runtime.h>
+#include "medscan.h"
+
+namespace ms {
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf<unsigned short>(const unsigned short *p) {     // bf16 bits
+    return __builtin_bit_cast(float, (unsigned)(*p) << 16);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_nhwc_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                       float *__restrict__ y, int C, int H, int W, int64_t xps, int rows) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);          // b*H + h
+    if (row >= rows) return;
+    const bool cv = c < C;
+    const int cc = cv ? c : C - 1;
+    const int h = row % H;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[cc * 9 + i];
+    const float bv = bias ? bias[cc] : 0.0f;
+    const T *r1 = x + (int64_t)row * W * xps + cc;                  // row h
+    const T *r0 = r1 - (int64_t)W * xps, *r2 = r1 + (int64_t)W * xps;
+    const bool v0 = h > 0, v2 = h < H - 1;
+    float a0 = 0, a1 = 0, a2 = 0, b0, b1, b2, c0, c1, c2;          // columns w-1 (a), w (b), w+1 (c)
+    b0 = v0 ? ldf(r0) : 0.0f; b1 = ldf(r1); b2 = v2 ? ldf(r2) : 0.0f;
+    float *yo = y + (int64_t)row * W * C + c;
+    for (int ww = 0; ww < W; ++ww) {
+        if (ww + 1 < W) {
+            const int64_t o = (int64_t)(ww + 1) * xps;
+            c0 = v0 ? ldf(r0 + o) : 0.0f; c1 = ldf(r1 + o); c2 = v2 ? ldf(r2 + o) : 0.0f;
+        } else { c0 = c1 = c2 = 0.0f; }
+        float acc = bv;
+        acc = fmaf(k[0], a0, acc); acc = fmaf(k[1], b0, acc); acc = fmaf(k[2], c0, acc);
+        acc = fmaf(k[3], a1, acc); acc = fmaf(k[4], b1, acc); acc = fmaf(k[5], c1, acc);
+        acc = fmaf(k[6], a2, acc); acc = fmaf(k[7], b2, acc); acc = fmaf(k[8], c2, acc);
+        if (cv) yo[(int64_t)ww * C] = acc * sigm(acc);
+        a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+    }
+}
+
+// Backward, pass 1: dpre = dy * silu'(conv(x) + b) for one image row (same sliding window as the forward: 3 loads
+// per pixel), stored to a scratch tensor; the parameter gradients dw[c, 0..8], dbias[c] are accumulated per lane over the
+// row and added with one atomic per (row, channel).
+constexpr int kRowsPerWaveBwd1 = 2;      // rows per wave in pass 1; with the 4-wave LDS combine: 8x fewer same-address atomics
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                        const float *__restrict__ dy, float *__restrict__ dpre, float *__restrict__ dw,
+                        float *__restrict__ dbias, int C, int H, int W, int64_t xps, int rows) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ float red[3][10][64];
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int row_first = (blockIdx.y * 4 + wv) * kRowsPerWaveBwd1;
+    const bool cv = c < C;
+    const int cc = cv ? c : C - 1;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[cc * 9 + i];
+    const float bv = bias ? bias[cc] : 0.0f;
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.0f;
+    const int row_end = min(rows, row_first + kRowsPerWaveBwd1);
+    for (int row = row_first; row < row_end; ++row) {
+        const int h = row % H;
+        const T *r1 = x + (int64_t)row * W * xps + cc;
+        const T *r0 = r1 - (int64_t)W * xps, *r2 = r1 + (int64_t)W * xps;
+        const bool v0 = h > 0, v2 = h < H - 1;
+        float a0 = 0, a1 = 0, a2 = 0, b0, b1, b2, c0, c1, c2;
+        b0 = v0 ? ldf(r0) : 0.0f; b1 = ldf(r1); b2 = v2 ? ldf(r2) : 0.0f;
+        const float *go = dy + (int64_t)row * W * C + cc;
+        float *po = dpre + (int64_t)row * W * C + c;
+        for (int ww = 0; ww < W; ++ww) {
+            if (ww + 1 < W) {
+                const int64_t o = (int64_t)(ww + 1) * xps;
+                c0 = v0 ? ldf(r0 + o) : 0.0f; c1 = ldf(r1 + o); c2 = v2 ? ldf(r2 + o) : 0.0f;
+            } else { c0 = c1 = c2 = 0.0f; }
+            const float g = go[(int64_t)ww * C];
+            float pre = bv;
+            pre = fmaf(k[0], a0, pre); pre = fmaf(k[1], b0, pre); pre = fmaf(k[2], c0, pre);
+            pre = fmaf(k[3], a1, pre); pre = fmaf(k[4], b1, pre); pre = fmaf(k[5], c1, pre);
+            pre = fmaf(k[6], a2, pre); pre = fmaf(k[7], b2, pre); pre = fmaf(k[8], c2, pre);
+            const float sg = sigm(pre);
+            const float dp = g * (sg * (1.0f + pre * (1.0f - sg)));
+            if (cv) po[(int64_t)ww * C] = dp;
+            acc[0] = fmaf(dp, a0, acc[0]); acc[1] = fmaf(dp, b0, acc[1]); acc[2] = fmaf(dp, c0, acc[2]);
+            acc[3] = fmaf(dp, a1, acc[3]); acc[4] = fmaf(dp, b1, acc[4]); acc[5] = fmaf(dp, c1, acc[5]);
+            acc[6] = fmaf(dp, a2, acc[6]); acc[7] = fmaf(dp, b2, acc[7]); acc[8] = fmaf(dp, c2, acc[8]);
+            acc[9] += dp;
+            a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+        }
+    }
+    // combine the block's 4 waves (same channels, different rows) in LDS, then one atomic per (block, channel, tap)
+    if (wv > 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) red[wv - 1][i][ln] = acc[i];
+    }
+    __syncthreads();
+    if (wv == 0 && cv) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] += red[0][i][ln] + red[1][i][ln] + red[2][i][ln];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(dw + c * 9 + i, acc[i]);
+        if (dbias) atomicAdd(dbias + c, acc[9]);
+    }
+}
+
+// Backward, pass 2: dx = conv3x3^T(dpre): dx[h][w] = sum_{i,j} dpre[h+1-i][w+1-j] * k[i][j]  (a correlation with the
+// flipped kernel: again a 3-row sliding window).
+__global__ void __launch_bounds__(256)
+dwconv_nhwc_bwd2_kernel(const float *__restrict__ dpre, const float *__restrict__ w, float *__restrict__ dx,
+                        int C, int H, int W, int rows) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bool cv = c < C;
+    const int cc = cv ? c : C - 1;
+    const int h = row % H;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[cc * 9 + i];
+    const float *r1 = dpre + (int64_t)row * W * C + cc;
+    const float *r0 = r1 - (int64_t)W * C, *r2 = r1 + (int64_t)W * C;
+    const bool v0 = h > 0, v2 = h < H - 1;
+    float a0 = 0, a1 = 0, a2 = 0, b0, b1, b2, c0, c1, c2;          // dpre columns w-1 (a), w (b), w+1 (c); rows h-1,h,h+1
+    b0 = v0 ? r0[0] : 0.0f; b1 = r1[0]; b2 = v2 ? r2[0] : 0.0f;
+    float *xo = dx + (int64_t)row * W * C + c;
+    for (int ww = 0; ww < W; ++ww) {
+        if (ww + 1 < W) {
+            const int64_t o = (int64_t)(ww + 1) * C;
+            c0 = v0 ? r0[o] : 0.0f; c1 = r1[o]; c2 = v2 ? r2[o] : 0.0f;
+        } else { c0 = c1 = c2 = 0.0f; }
+        // i = 0 -> row h+1 (x2), i = 2 -> row h-1 (x0);  j = 0 -> column w+1 (c), j = 2 -> column w-1 (a)
+        float a = 0.0f;
+        a = fmaf(k[0], c2, a); a = fmaf(k[1], b2, a); a = fmaf(k[2], a2, a);
+        a = fmaf(k[3], c1, a); a = fmaf(k[4], b1, a); a = fmaf(k[5], a1, a);
+        a = fmaf(k[6], c0, a); a = fmaf(k[7], b0, a); a = fmaf(k[8], a0, a);
+        if (cv) xo[(int64_t)ww * C] = a;
+        a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+    }
+}
+
+template <typename T>
+static int launch_fwd(const void *x, const float *w, const float *bias, float *y, int batch, int C, int H, int W,
+                      int64_t xps, hipStream_t s) {
+    const int rows = batch * H;
+    hipLaunchKernelGGL((dwconv_nhwc_fwd_kernel<T>), dim3((C + 63) / 64, (rows + 3) / 4, 1), dim3(256), 0, s,
+                       (const T *)x, w, bias, y, C, H, W, xps, rows);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
+                             int batch, int C, int H, int W, int64_t xps, hipStream_t s) {
+    if (!x || !w || !y) return MS_ERR_NULL;
+    if (batch < 0 || C <= 0 || H <= 0 || W <= 0 || xps < C) return MS_ERR_SHAPE;
+    if (batch == 0) return MS_OK;
+    return x_is_bf16 ? launch_fwd<unsigned short>(x, w, bias, y, batch, C, H, W, xps, s)
+                     : launch_fwd<float>(x, w, bias, y, batch, C, H, W, xps, s);
+}
+
+template <typename T>
+static int launch_bwd(const void *x, const float *w, const float *bias, const float *dy, float *dx, float *scratch,
+                      float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s) {
+    const int rows = batch * H;
+    // dx doubles as the dpre scratch of pass 1?  No: pass 2 reads rows h-1..h+1 of dpre while writing row h of dx,
+    // so dpre needs its own buffer -- the caller passes it in `dx_scratch` (same shape as dx).
+    const int tasks = (rows + kRowsPerWaveBwd1 - 1) / kRowsPerWaveBwd1;
+    hipLaunchKernelGGL((dwconv_nhwc_bwd1_kernel<T>), dim3((C + 63) / 64, (tasks + 3) / 4, 1), dim3(256), 0, s,
+                       (const T *)x, w, bias, dy, scratch, dw, dbias, C, H, W, xps, rows);
+    hipLaunchKernelGGL((dwconv_nhwc_bwd2_kernel), dim3((C + 63) / 64, (rows + 3) / 4, 1), dim3(256), 0, s,
+                       scratch, w, dx, C, H, W, rows);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
+                             float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
+                             int64_t xps, hipStream_t s) {
+    if (!x || !w || !dy || !dx || !dw || !scratch) return MS_ERR_NULL;
+    if (batch < 0 || C <= 0 || H <= 0 || W <= 0 || xps < C) return MS_ERR_SHAPE;
+    if (batch == 0) return MS_OK;
+    return x_is_bf16 ? launch_bwd<unsigned short>(x, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W, xps, s)
+                     : launch_bwd<float>(x, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W, xps, s);
+}
+
+}  // namespace ms

@@ -11,6 +11,7 @@ selective scan (fwd/bwd) and the cross-merge are hand-written gfx950 kernels rea
 (include/medscan.h); there is no CPU path -- CPU tensors raise RuntimeError.
 """
 import math
+import os
 from functools import partial
 from typing import Callable
 
@@ -21,7 +22,12 @@ import torch.utils.checkpoint as checkpoint
 
 from . import _lib
 from .selective_scan_interface import selective_scan_fn
+from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu
+
+# The channel-last fused core is the default path of SS2D.forward; MEDSCAN_FUSED=0 selects the layout-faithful path
+# (NCHW conv, materialised cross-scan/merge) that mirrors the reference's data flow op by op.
+FUSED = os.environ.get("MEDSCAN_FUSED", "1") != "0"
 
 
 class DropPath(nn.Module):
@@ -196,17 +202,24 @@ class SS2D(nn.Module):
         _lib.require_cuda(x)
         B, H, W, C = x.shape
         xz = self.in_proj(x)
-        x, z = xz.chunk(2, dim=-1)                                  # (B,H,W,D) each
-        x = x.permute(0, 3, 1, 2).contiguous()
-        x = dwconv3x3_silu(x, self.conv2d.weight, self.conv2d.bias)  # (B,D,H,W) fp32
-        if getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0:
-            self.selective_scan = selective_scan_fn
-            y = cross_merge(self._scan(x), H, W)                    # (B,D,L) = y1+y2+y3+y4, one kernel
-        else:                                                       # user-supplied core: reference data flow
-            y1, y2, y3, y4 = self.forward_core(x)
-            assert y1.dtype == torch.float32
-            y = y1 + y2 + y3 + y4
-        y = y.transpose(1, 2).contiguous().view(B, H, W, -1)
+        x, z = xz.chunk(2, dim=-1)                                  # (B,H,W,D) each, views of xz
+        default_core = getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0
+        if FUSED and default_core and self.d_conv == 3:
+            # channel-last fused core: conv reads xz in place, the scan kernel applies the 4 direction maps itself
+            xc = dwconv3x3_silu_nhwc(x, self.conv2d.weight, self.conv2d.bias)
+            y = ss2d_core(xc, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
+                          self.d_state, self.dt_rank)               # (B,H,W,D) fp32
+        else:
+            x = x.permute(0, 3, 1, 2).contiguous()
+            x = dwconv3x3_silu(x, self.conv2d.weight, self.conv2d.bias)  # (B,D,H,W) fp32
+            if default_core:
+                self.selective_scan = selective_scan_fn
+                y = cross_merge(self._scan(x), H, W)                # (B,D,L) = y1+y2+y3+y4, one kernel
+            else:                                                   # user-supplied core: reference data flow
+                y1, y2, y3, y4 = self.forward_core(x)
+                assert y1.dtype == torch.float32
+                y = y1 + y2 + y3 + y4
+            y = y.transpose(1, 2).contiguous().view(B, H, W, -1)
         y = self.out_norm(y)
         y = y * F.silu(z)
         out = self.out_proj(y)

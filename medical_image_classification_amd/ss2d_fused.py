@@ -1,0 +1,154 @@
+"""Channel-last fused core of SS2D (what sits between in_proj and out_norm in MedMamba.py:466-483).
+
+The reference permutes to NCHW, materialises the four scan orders (stack/transpose/flip/cat), runs the projections on
+those copies, scans, and un-permutes/merges with more copies (MedMamba.py:393-424,472-477).  x_proj and dt_proj are
+pointwise per pixel, so here every tensor stays in PIXEL order, channel-last:
+
+    xc    (B,H,W,D)   = SiLU(dwconv3x3(x) + b)                      ms_dwconv3x3_silu_nhwc_*  (reads xz in place)
+    P     (B,L,4,C)   = xc @ x_proj_weight.view(4C, D)^T            C = R + 2N: [dts | Bs | Cs] of every direction
+    delta (4,B,L,D)   = P[..., k, :R] @ dt_projs_weight[k]^T        (bias + softplus inside the scan kernel)
+    y     (B,L,D)     = sum_k scan_k(...)                           ms_selective_scan_fwd in SS2D mode: direction k visits
+                                                                    the pixels in the order of MedMamba.py:393-395, all
+                                                                    four read the same xc (group stride 0) and write
+                                                                    their result back in pixel order
+so cross-scan and cross-merge cost no memory traffic at all, and nothing is ever transposed.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MsScanBwdParams, MsScanParams
+from .selective_scan_interface import TIMER, algorithmic_bytes
+
+
+class _DWConvSiLUNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        """x: (B,H,W,C) view with unit channel stride and a uniform pixel stride (e.g. one half of xz); fp32 or bf16."""
+        _lib.require_cuda(x, weight, bias)
+        B, H, W, C = x.shape
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        ps = x.stride(2)
+        if x.stride(3) != 1 or x.stride(1) != W * ps or x.stride(0) != H * W * ps:
+            x = x.contiguous(); ps = C
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous() if bias is not None else None
+        y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_fwd(
+                x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr() if b is not None else None,
+                y.data_ptr(), B, C, H, W, ps, _lib.current_stream_ptr(x.device)), "ms_dwconv3x3_silu_nhwc_fwd")
+        ctx.save_for_backward(x, w, b)
+        ctx.ps, ctx.wdtype, ctx.bdtype = ps, weight.dtype, (bias.dtype if bias is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+        scratch = torch.empty_like(dx)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b) if b is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd(
+                x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr() if b is not None else None,
+                dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                B, C, H, W, ctx.ps, _lib.current_stream_ptr(x.device)), "ms_dwconv3x3_silu_nhwc_bwd")
+        return dx.to(x.dtype), dw.to(ctx.wdtype), (db.to(ctx.bdtype) if db is not None else None)
+
+
+def dwconv3x3_silu_nhwc(x, weight, bias):
+    """SiLU(depthwise conv3x3(x) + bias) on a channel-last (B,H,W,C) tensor -> (B,H,W,C) fp32."""
+    return _DWConvSiLUNHWC.apply(x, weight, bias)
+
+
+def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R):
+    B, L, D = xc.shape[0], H * W, xc.shape[-1]
+    C = R + 2 * N
+    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = B, 4 * D, L, N, 4
+    P.delta_softplus, P.map_h, P.map_w = 1, H, W
+    P.u_batch_stride, P.u_group_stride, P.u_d_stride, P.u_l_stride = L * D, 0, 1, D
+    P.delta_batch_stride, P.delta_group_stride, P.delta_d_stride, P.delta_l_stride = L * D, B * L * D, 1, D
+    P.out_batch_stride, P.out_group_stride, P.out_d_stride, P.out_l_stride = L * D, B * L * D, 1, D
+    P.A_d_stride, P.A_dstate_stride = N, 1
+    P.B_batch_stride, P.B_group_stride, P.B_dstate_stride, P.B_l_stride = L * 4 * C, C, 1, 4 * C
+    P.C_batch_stride, P.C_group_stride, P.C_dstate_stride, P.C_l_stride = L * 4 * C, C, 1, 4 * C
+    P.u, P.delta, P.A = xc.data_ptr(), delta.data_ptr(), A.data_ptr()
+    P.B, P.C = proj.data_ptr() + 4 * R, proj.data_ptr() + 4 * (R + N)
+    P.D, P.delta_bias = Ds.data_ptr(), dt_bias.data_ptr()
+    P.out = out.data_ptr() if out is not None else None
+    P.x = x_state.data_ptr()
+
+
+class _SS2DScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xc, proj, delta, A, Ds, dt_bias, H, W, N, R):
+        """xc (B,H,W,D), proj (B,L,4,R+2N), delta (4,B,L,D), A (4D,N), Ds (4D), dt_bias (4D): fp32 contiguous.
+        Returns y (B,L,D) = ((y0 + y2) + y1) + y3 with every y_k in pixel order (add order of MedMamba.py:476)."""
+        _lib.require_cuda(xc, proj, delta, A, Ds, dt_bias)
+        lib = _lib.lib()
+        B, D, L = xc.shape[0], xc.shape[-1], H * W
+        xc, proj, delta = xc.contiguous(), proj.contiguous(), delta.contiguous()
+        A, Ds, dt_bias = A.contiguous(), Ds.contiguous(), dt_bias.contiguous()
+        y4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
+        x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=xc.device, dtype=torch.float32)
+        P = MsScanParams()
+        _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R)
+        with torch.cuda.device(xc.device):
+            rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
+                              lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(xc.device)))
+            _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
+        ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state)
+        ctx.geom = (H, W, N, R)
+        return (y4[0] + y4[2]) + y4[1] + y4[3]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, proj, delta, A, Ds, dt_bias, x_state = ctx.saved_tensors
+        H, W, N, R = ctx.geom
+        lib = _lib.lib()
+        B, D, L = xc.shape[0], xc.shape[-1], H * W
+        C = R + 2 * N
+        dy = dy.contiguous().float()                              # (B,L,D): dout of all four directions (group stride 0)
+        du4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
+        ddelta = torch.empty_like(du4)
+        dproj = torch.zeros_like(proj)
+        dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Ds), torch.zeros_like(dt_bias)
+        Q = MsScanBwdParams()
+        _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R)
+        Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
+        Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, B * L * D, 1, D
+        Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * D, B * L * D, 1, D
+        Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = L * 4 * C, C, 1, 4 * C
+        Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = L * 4 * C, C, 1, 4 * C
+        Q.dout, Q.du, Q.ddelta = dy.data_ptr(), du4.data_ptr(), ddelta.data_ptr()
+        Q.dA, Q.dD, Q.ddelta_bias = dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
+        Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
+        with torch.cuda.device(xc.device):
+            rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), xc.device,
+                              lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(xc.device)))
+            _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
+        dxc = du4.sum(dim=0).view_as(xc)
+        return dxc, dproj, ddelta, dA, dD, dbias, None, None, None, None
+
+
+def ss2d_core(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, d_state, dt_rank):
+    """xc (B,H,W,D) fp32 -> merged scan output y (B,H,W,D) fp32.  The x_proj GEMM follows the ambient autocast
+    (bf16 under autocast, like the reference's einsum would, MedMamba.py:397); dt_proj (K = R <= 24) and the scan are
+    fp32 always (MedMamba.py:403-409).  Parameters keep their reference shapes."""
+    B, H, W, D = xc.shape
+    N, R = d_state, dt_rank
+    C = R + 2 * N
+    M = B * H * W
+    proj = torch.mm(xc.view(M, D), x_proj_weight.view(4 * C, D).t()).float()                # (M, 4C)
+    with torch.autocast(device_type="cuda", enabled=False):
+        dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                   # (4, M, R)
+        delta = torch.bmm(dts, dt_projs_weight.float().transpose(1, 2))                     # (4, M, D)
+        As = -torch.exp(A_logs.float())                                                      # (4D, N)
+        y = _SS2DScan.apply(xc, proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D), As, Ds.float().view(-1),
+                            dt_projs_bias.float().view(-1), H, W, N, R)
+    return y.view(B, H, W, D)

@@ -169,4 +169,63 @@ def test_medmamba_t_stage_block_vs_oracle():
     pr = dict(ref.named_parameters())
     for k, p in blk.named_parameters():
         r = pr[k].grad.numpy()
-        assert_close(p.grad, r, 1e-2, 1e-3 * max(1e-3, float(np.abs(r).max())), k)
+        # absolute floor 1e-4: conv biases that feed a BatchNorm have a mathematically zero gradient (both sides are
+        # rounding noise of ~1e-5 there)
+        # the dense-conv branch (MIOpen vs oneDNN weight-gradient algorithms) is not ours: loose bound there
+        loose = k.startswith("conv33conv33conv11")
+        assert_close(p.grad, r, 5e-2 if loose else 1e-2, max(1e-4, (2e-2 if loose else 1e-3) * float(np.abs(r).max())), k)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (2, 24, 7, 5), (1, 3, 5, 9), (1, 70, 1, 1), (1, 130, 3, 4)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_dwconv_nhwc_vs_torch(shape, bf16):
+    """Channel-last conv reading one half of a (B,H,W,2C) tensor in place, fp32 and bf16 inputs."""
+    from medical_image_classification_amd.ss2d_fused import dwconv3x3_silu_nhwc
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(4)
+    xz = torch.randn(B, H, W, 2 * C, generator=gen)
+    if bf16:
+        xz = xz.bfloat16().float()
+    w = torch.randn(C, 1, 3, 3, generator=gen) * 0.5; b = torch.randn(C, generator=gen)
+    g = torch.randn(B, H, W, C, generator=gen)
+    xr = xz[..., :C].permute(0, 3, 1, 2).double().requires_grad_(); wr = w.double().requires_grad_(); br = b.double().requires_grad_()
+    ref = F.silu(F.conv2d(xr, wr, br, padding=1, groups=C))
+    ref.backward(g.permute(0, 3, 1, 2).double())
+    xzd = xz.to(dev(), torch.bfloat16 if bf16 else torch.float32).requires_grad_()
+    wd, bd = w.to(dev()).requires_grad_(), b.to(dev()).requires_grad_()
+    y = dwconv3x3_silu_nhwc(xzd[..., :C], wd, bd)
+    assert y.shape == (B, H, W, C) and y.dtype == torch.float32
+    y.backward(g.to(dev()))
+    assert_close(y, ref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, 1e-5, "y")
+    tol = 1e-2 if bf16 else 1e-4                                   # dx comes back in the input's dtype
+    assert_close(xzd.grad[..., :C], xr.grad.permute(0, 2, 3, 1).numpy(), tol, tol, "dx")
+    assert float(xzd.grad[..., C:].abs().max()) == 0.0
+    sc = max(1.0, float(wr.grad.abs().max()))
+    assert_close(wd.grad, wr.grad.numpy(), 1e-4, 1e-4 * sc, "dw")
+    assert_close(bd.grad, br.grad.numpy(), 1e-4, 1e-4 * sc, "db")
+
+
+@pytest.mark.parametrize("cfg", [(16, 6, 9, 2), (48, 14, 14, 2), (96, 28, 28, 1), (12, 5, 7, 2), (8, 1, 1, 1), (20, 33, 2, 1)])
+def test_fused_core_matches_layout_faithful_path(cfg, monkeypatch):
+    """SS2D.forward through the channel-last fused core == the NCHW / materialised cross-scan path (same kernels'
+    reference-layout mode), forward and all gradients."""
+    from medical_image_classification_amd import medmamba as mm
+    d_model, H, W, B = cfg
+    torch.manual_seed(d_model + H)
+    blk = mm.SS2D(d_model=d_model).to(dev())
+    x = torch.randn(B, H, W, d_model, device=dev())
+    g = torch.randn(B, H, W, d_model, device=dev())
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(mm, "FUSED", fused)
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        y = blk(xi)
+        y.backward(g)
+        outs.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    (yf, dxf, gf), (yu, dxu, gu) = outs
+    sc = lambda t: max(1e-3, float(t.abs().max()))
+    assert float((yf - yu).abs().max()) <= 1e-4 * sc(yu)
+    assert float((dxf - dxu).abs().max()) <= 5e-4 * sc(dxu)
+    for k in gu:
+        assert float((gf[k] - gu[k]).abs().max()) <= 2e-3 * sc(gu[k]), k
