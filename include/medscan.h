@@ -137,6 +137,21 @@ int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, con
                                float *dx, float *scratch /* (batch,H,W,C) fp32 work buffer */, float *dw, float *dbias,
                                int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream);
 
+/*
+ * Fused tail of SS2D (MedMamba.py:476-479): cross-merge sum of the four directions + LayerNorm(D) + SiLU gate.
+ *   y4   : 4 scan outputs in pixel order, y_k at y4 + k*dir_stride, each (npix, D) contiguous fp32
+ *   z    : gate, (npix, *) fp32 or bf16 (z_is_bf16) with pixel stride z_pixel_stride (reads the z half of xz in place)
+ *   out  = (LN(((y0+y2)+y1)+y3) * gamma + beta) * silu(z)      (npix, D) contiguous, fp32 or bf16 (out_is_bf16)
+ * bwd: dout (npix, D) fp32|bf16 -> dy (npix, D) fp32 (the dout of all four scan directions), dz (npix, D) in z's
+ *      dtype, and ACCUMULATES dgamma, dbeta (D).  y and the LN statistics are recomputed from y4.
+ */
+int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                   const float *gamma, const float *beta, float eps, void *out, int out_is_bf16,
+                   int64_t npix, int D, void *stream);
+int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                   const float *gamma, const float *beta, float eps, const void *dout, int dout_is_bf16,
+                   float *dy, void *dz, float *dgamma, float *dbeta, int64_t npix, int D, void *stream);
+
 int ms_abi_version(void);
 const char *ms_status_string(int status);
 

@@ -48,7 +48,7 @@ class MsScanBwdParams(ctypes.Structure):
 
 EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_cross_scan",
            "ms_cross_merge", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_dwconv3x3_silu_nhwc_fwd",
-           "ms_dwconv3x3_silu_nhwc_bwd", "ms_abi_version", "ms_status_string")
+           "ms_dwconv3x3_silu_nhwc_bwd", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_abi_version", "ms_status_string")
 
 _lib = None
 
@@ -88,6 +88,10 @@ def lib():
     h.ms_dwconv3x3_silu_bwd.argtypes = [c_vp] * 7 + [ctypes.c_int] * 4 + [c_vp]
     h.ms_dwconv3x3_silu_nhwc_fwd.argtypes = [c_vp, ctypes.c_int] + [c_vp] * 3 + [ctypes.c_int] * 4 + [c_i64, c_vp]
     h.ms_dwconv3x3_silu_nhwc_bwd.argtypes = [c_vp, ctypes.c_int] + [c_vp] * 7 + [ctypes.c_int] * 4 + [c_i64, c_vp]
+    c_f, c_int = ctypes.c_float, ctypes.c_int
+    h.ms_ln_gate_fwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_i64, c_int, c_vp]
+    h.ms_ln_gate_bwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
+                                 c_i64, c_int, c_vp]
     h.ms_status_string.restype = ctypes.c_char_p
     h.ms_status_string.argtypes = [ctypes.c_int]
     for name in EXPORTS[:-1]:

@@ -17,6 +17,11 @@ int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const
 int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
                              float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
                              int64_t xps, hipStream_t s);
+int ln_gate_fwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
+                         const float *beta, float eps, void *out, int out_bf16, int64_t npix, int D, hipStream_t s);
+int ln_gate_bwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
+                         const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz,
+                         float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
 }  // namespace ms
 
 extern "C" {
@@ -61,6 +66,20 @@ int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, con
                                int64_t x_pixel_stride, void *stream) {
     return ms::dwconv_nhwc_bwd_dispatch(x, x_is_bf16, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W,
                                         x_pixel_stride, (hipStream_t)stream);
+}
+
+int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                   const float *gamma, const float *beta, float eps, void *out, int out_is_bf16,
+                   int64_t npix, int D, void *stream) {
+    return ms::ln_gate_fwd_dispatch(y4, dir_stride, z, z_is_bf16, z_pixel_stride, gamma, beta, eps, out, out_is_bf16,
+                                    npix, D, (hipStream_t)stream);
+}
+
+int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                   const float *gamma, const float *beta, float eps, const void *dout, int dout_is_bf16,
+                   float *dy, void *dz, float *dgamma, float *dbeta, int64_t npix, int D, void *stream) {
+    return ms::ln_gate_bwd_dispatch(y4, dir_stride, z, z_is_bf16, z_pixel_stride, gamma, beta, eps, dout, dout_is_bf16,
+                                    dy, dz, dgamma, dbeta, npix, D, (hipStream_t)stream);
 }
 
 int ms_abi_version(void) { return MEDSCAN_ABI_VERSION; }

@@ -88,6 +88,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     __shared__ float sg_[kTile];      // dout tile   -> ddelta tile
     __shared__ float sck[NB * NPL * 64];   // h at the start of each 4-position batch
     __shared__ float sbias[kCW];
+    __shared__ int spos[2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
     const int lane = threadIdx.x;
     const int c = lane % CW, sg = lane / CW;
 
@@ -132,6 +133,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     PosMap pm;
     pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.H = p.map_h; pm.W = p.map_w; pm.L = L;
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
+    pm.tab = nullptr; pm.tab_base = 0;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     float *dBb = q.dB + b * q.dB_batch_stride + g * q.dB_group_stride;
@@ -144,6 +146,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float ru[Tile::NE], rd[Tile::NE], rg[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
+        if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
         tile.fetch(ru, ub, p.u_d_stride, p.u_l_stride, l0, pm, nvalid, len);
         tile.fetch(rd, db, p.delta_d_stride, p.delta_l_stride, l0, pm, nvalid, len);
         tile.fetch(rg, gb, q.dout_d_stride, q.dout_l_stride, l0, pm, nvalid, len);
@@ -264,11 +267,16 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             }
         }
         wave_sync();
+        if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
         tile.store(su, dub, q.du_d_stride, q.du_l_stride, l0, pm, nvalid, len);
         tile.store(sg_, ddb, q.ddelta_d_stride, q.ddelta_l_stride, l0, pm, nvalid, len);
         // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
-        rows.flush_add(sdB, dBb, q.dB_dstate_stride, q.dB_l_stride, l0, pm, N, len);
-        rows.flush_add(sdC, dCb, q.dC_dstate_stride, q.dC_l_stride, l0, pm, N, len);
+        if (MODE == kModeSS2D && dCb == dBb + N && q.dB_l_stride == q.dC_l_stride) {
+            rows.flush_add_pair(sdB, sdC, dBb, q.dB_l_stride, pm, N, len);
+        } else {
+            rows.flush_add(sdB, dBb, q.dB_dstate_stride, q.dB_l_stride, l0, pm, N, len);
+            rows.flush_add(sdC, dCb, q.dC_dstate_stride, q.dC_l_stride, l0, pm, N, len);
+        }
         wave_sync();
     }
 

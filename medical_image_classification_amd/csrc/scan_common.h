@@ -63,6 +63,13 @@ __device__ __forceinline__ void wave_sync() {
 struct PosMap {
     int mode, H, W, L;
     float invH;
+    const int *tab;        // SS2D mode: LDS table of the current chunk's kCL positions (filled by fill_table)
+    int tab_base;          // first sequence index the table covers
+    __device__ __forceinline__ int at(int l) const { return tab[l - tab_base]; }      // l inside the current chunk
+    __device__ __forceinline__ void fill_table(int *t, int lbase, int lane) {
+        if (lane < kCL) t[lane] = (*this)(min(lbase + lane, L - 1));
+        tab = t; tab_base = lbase;
+    }
     __device__ __forceinline__ int operator()(int l) const {
         if (mode < 0) return l;
         int t = (mode & 2) ? L - 1 - l : l;
@@ -101,7 +108,7 @@ struct TileIO {
     __device__ __forceinline__ int lk(int k) const { return LCONTIG ? l0_ : l0_ + k * STEP; }
     __device__ __forceinline__ int ck(int k) const { return LCONTIG ? c0_ + k * STEP : c0_; }
     __device__ __forceinline__ uint32_t goff(int k, int64_t sd, int64_t sl, int lbase, const PosMap &pm) const {
-        const int pos = MODE == kModeSS2D ? pm(lbase + lk(k)) : lbase + lk(k);
+        const int pos = MODE == kModeSS2D ? pm.tab[lk(k)] : lbase + lk(k);
         return (uint32_t)(ck(k) * (int)sd + pos * (int)sl) * 4u;
     }
     __device__ __forceinline__ bool ok(int k, int nvalid, int len) const { return lk(k) < len && ck(k) < nvalid; }
@@ -121,7 +128,7 @@ struct TileIO {
     }
     // byte offset of an element that is always inside the tensor: (first position of the chunk, channel 0)
     __device__ __forceinline__ uint32_t first_valid(int64_t sd, int64_t sl, int lbase, const PosMap &pm) const {
-        const int pos = MODE == kModeSS2D ? pm(lbase) : lbase;
+        const int pos = MODE == kModeSS2D ? pm.tab[0] : lbase;
         return (uint32_t)(pos * (int)sl) * 4u;
     }
     __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
@@ -161,13 +168,13 @@ struct RowIO {
     __device__ __forceinline__ int nk(int k) const { return NCONTIG ? (lane_ + 64 * k) % NP : lane_ / kCL + 2 * k; }
     __device__ __forceinline__ int lk(int k) const { return NCONTIG ? (lane_ + 64 * k) / NP : lane_ % kCL; }
     __device__ __forceinline__ uint32_t goff(int k, int64_t sn, int64_t sl, int lbase, const PosMap &pm) const {
-        const int pos = NCONTIG ? pm(lbase + lk(k)) : lbase + lk(k);
+        const int pos = NCONTIG ? pm.tab[lk(k)] : lbase + lk(k);
         return (uint32_t)(nk(k) * (int)sn + pos * (int)sl) * 4u;
     }
     __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sn, int64_t sl, int lbase,
                                           const PosMap &pm, int N, int len) const {
         const char *b = reinterpret_cast<const char *>(base);
-        const uint32_t safe = (uint32_t)((NCONTIG ? pm(lbase) : lbase) * (int)sl) * 4u;     // (state 0, first position)
+        const uint32_t safe = (uint32_t)((NCONTIG ? pm.tab[0] : lbase) * (int)sl) * 4u;     // (state 0, first position)
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const bool v = nk(k) < N && lk(k) < len;
@@ -178,6 +185,22 @@ struct RowIO {
     __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
 #pragma unroll
         for (int k = 0; k < NE; ++k) s[nk(k) * kRowPitch + lk(k)] = r[k];
+    }
+    // SS2D mode: dB and dC of one pixel are adjacent in the projection-gradient row ([.. | B(N) | C(N)]), so both staged
+    // tiles are flushed together: lane idx -> (t = idx % 2NP, l = idx / 2NP), 2N*4-byte atomic segments per pixel.
+    __device__ __forceinline__ void flush_add_pair(const float *sB, const float *sC, float *baseB, int64_t sl,
+                                                   const PosMap &pm, int N, int len) const {
+        char *b = reinterpret_cast<char *>(baseB);
+#pragma unroll
+        for (int k = 0; k < 2 * NE; ++k) {
+            const int idx = lane_ + 64 * k, t = idx % (2 * NP), l = idx / (2 * NP);
+            const bool isC = t >= NP;
+            const int n = isC ? t - NP : t;
+            if (n < N && l < len) {
+                const uint32_t off = (uint32_t)(pm.tab[l] * (int)sl + n + (isC ? N : 0)) * 4u;
+                atomicAdd(reinterpret_cast<float *>(b + off), (isC ? sC : sB)[n * kRowPitch + l]);
+            }
+        }
     }
     // accumulate a staged [n][l] tile into global memory (dB / dC of the backward)
     __device__ __forceinline__ void flush_add(const float *s, float *base, int64_t sn, int64_t sl, int lbase,

@@ -26,6 +26,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     __shared__ float su[kTile];       // u tile, overwritten in place by the out tile
     __shared__ float sdl[kTile];      // delta' tile
     __shared__ float sbias[kCW];
+    __shared__ int spos[2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
     const int lane = threadIdx.x;
     const int c = lane % CW, sg = lane / CW;
 
@@ -65,6 +66,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     PosMap pm;
     pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.H = p.map_h; pm.W = p.map_w; pm.L = L;
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
+    pm.tab = nullptr; pm.tab_base = 0;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = p.delta_softplus != 0;
@@ -75,6 +77,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     float ru[Tile::NE], rd[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
+        if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
         tile.fetch(ru, ub, p.u_d_stride, p.u_l_stride, l0, pm, nvalid, len);
         tile.fetch(rd, db, p.delta_d_stride, p.delta_l_stride, l0, pm, nvalid, len);
         rows.fetch(rB, Bb, p.B_dstate_stride, p.B_l_stride, l0, pm, N, len);
@@ -126,6 +129,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
             }
         }
         wave_sync();
+        if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
         tile.store(su, ob, p.out_d_stride, p.out_l_stride, l0, pm, nvalid, len);
         wave_sync();
     }

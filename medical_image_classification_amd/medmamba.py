@@ -22,12 +22,15 @@ import torch.utils.checkpoint as checkpoint
 
 from . import _lib
 from .selective_scan_interface import selective_scan_fn
-from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core
+from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu
 
 # The channel-last fused core is the default path of SS2D.forward; MEDSCAN_FUSED=0 selects the layout-faithful path
 # (NCHW conv, materialised cross-scan/merge) that mirrors the reference's data flow op by op.
 FUSED = os.environ.get("MEDSCAN_FUSED", "1") != "0"
+# The dense-conv branch of SS_Conv_SSM consumes and produces NHWC tokens; with channels_last the two permute copies
+# around it (MedMamba.py:533,535) become views and MIOpen runs its NHWC kernels.
+CONV_CHANNELS_LAST = os.environ.get("MEDSCAN_CONV_CL", "1") == "1"
 
 
 class DropPath(nn.Module):
@@ -204,8 +207,13 @@ class SS2D(nn.Module):
         xz = self.in_proj(x)
         x, z = xz.chunk(2, dim=-1)                                  # (B,H,W,D) each, views of xz
         default_core = getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0
+        if FUSED and default_core and self.d_conv == 3 and type(self.out_norm) is nn.LayerNorm and self.d_inner <= 1024:
+            # channel-last fused core: the conv reads xz in place, the scan kernel applies the 4 direction maps itself,
+            # merge + out_norm + SiLU(z) gate are one kernel
+            xc = dwconv3x3_silu_nhwc(x, self.conv2d.weight, self.conv2d.bias)
+            out = self.out_proj(ss2d_core_norm_gate(xc, z, self))
+            return out if self.dropout is None else self.dropout(out)
         if FUSED and default_core and self.d_conv == 3:
-            # channel-last fused core: conv reads xz in place, the scan kernel applies the 4 direction maps itself
             xc = dwconv3x3_silu_nhwc(x, self.conv2d.weight, self.conv2d.bias)
             y = ss2d_core(xc, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
                           self.d_state, self.dt_rank)               # (B,H,W,D) fp32
@@ -261,8 +269,12 @@ class SS_Conv_SSM(nn.Module):
     def forward(self, input: torch.Tensor):
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))
-        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous())
-        left = left.permute(0, 2, 3, 1).contiguous()
+        if CONV_CHANNELS_LAST and left.is_cuda:
+            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+            left = left.permute(0, 2, 3, 1)                         # a view when the conv output is channels_last
+        else:
+            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous())
+            left = left.permute(0, 2, 3, 1).contiguous()
         out = channel_shuffle(torch.cat((left, x), dim=-1), groups=2)
         return out + input
 

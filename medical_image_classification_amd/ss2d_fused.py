@@ -136,10 +136,90 @@ class _SS2DScan(torch.autograd.Function):
         return dxc, dproj, ddelta, dA, dD, dbias, None, None, None, None
 
 
-def ss2d_core(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, d_state, dt_rank):
-    """xc (B,H,W,D) fp32 -> merged scan output y (B,H,W,D) fp32.  The x_proj GEMM follows the ambient autocast
-    (bf16 under autocast, like the reference's einsum would, MedMamba.py:397); dt_proj (K = R <= 24) and the scan are
-    fp32 always (MedMamba.py:403-409).  Parameters keep their reference shapes."""
+def _pixel_view(t, D):
+    """(B,H,W,D) tensor (possibly a channel slice of a wider tensor) -> (tensor, pixel stride) usable by the kernels."""
+    B, H, W, _ = t.shape
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    ps = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != W * ps or t.stride(0) != H * W * ps or ps < D:
+        t = t.contiguous(); ps = D
+    return t, ps
+
+
+class _SS2DScanNormGate(torch.autograd.Function):
+    """scan (4 directions, pixel order) -> merge sum + LayerNorm + SiLU(z) gate, as ONE autograd node: the four scan
+    outputs never pass through autograd, and the LayerNorm backward hands one (B,L,D) gradient to all four directions."""
+
+    @staticmethod
+    def forward(ctx, xc, proj, delta, A, Ds, dt_bias, z, gamma, beta, eps, H, W, N, R, out_bf16):
+        _lib.require_cuda(xc, proj, delta, A, Ds, dt_bias, z, gamma, beta)
+        lib = _lib.lib()
+        B, D, L = xc.shape[0], xc.shape[-1], H * W
+        xc, proj, delta = xc.contiguous(), proj.contiguous(), delta.contiguous()
+        A, Ds, dt_bias = A.contiguous(), Ds.contiguous(), dt_bias.contiguous()
+        gamma, beta = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        z, zps = _pixel_view(z, D)
+        y4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
+        x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=xc.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, D), device=xc.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        P = MsScanParams()
+        _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R)
+        stream = _lib.current_stream_ptr(xc.device)
+        with torch.cuda.device(xc.device):
+            rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
+                              lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
+            _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
+            _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, z.data_ptr(), int(z.dtype == torch.bfloat16), zps,
+                                          gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16),
+                                          B * L, D, stream), "ms_ln_gate_fwd")
+        ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state, y4, z, gamma, beta)
+        ctx.geom = (H, W, N, R, float(eps), zps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, proj, delta, A, Ds, dt_bias, x_state, y4, z, gamma, beta = ctx.saved_tensors
+        H, W, N, R, eps, zps = ctx.geom
+        lib = _lib.lib()
+        B, D, L = xc.shape[0], xc.shape[-1], H * W
+        C = R + 2 * N
+        if dout.dtype not in (torch.float32, torch.bfloat16):
+            dout = dout.float()
+        dout = dout.contiguous()
+        dy = torch.empty((B, L, D), device=xc.device, dtype=torch.float32)
+        dz = torch.empty((B, H, W, D), device=xc.device, dtype=z.dtype)
+        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(beta)
+        du4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
+        ddelta = torch.empty_like(du4)
+        dproj = torch.zeros_like(proj)
+        dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Ds), torch.zeros_like(dt_bias)
+        Q = MsScanBwdParams()
+        _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R)
+        Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
+        Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, B * L * D, 1, D
+        Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * D, B * L * D, 1, D
+        Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = L * 4 * C, C, 1, 4 * C
+        Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = L * 4 * C, C, 1, 4 * C
+        Q.dout, Q.du, Q.ddelta = dy.data_ptr(), du4.data_ptr(), ddelta.data_ptr()
+        Q.dA, Q.dD, Q.ddelta_bias = dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
+        Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
+        stream = _lib.current_stream_ptr(xc.device)
+        with torch.cuda.device(xc.device):
+            _lib.check(lib.ms_ln_gate_bwd(y4.data_ptr(), B * L * D, z.data_ptr(), int(z.dtype == torch.bfloat16), zps,
+                                          gamma.data_ptr(), beta.data_ptr(), eps, dout.data_ptr(),
+                                          int(dout.dtype == torch.bfloat16), dy.data_ptr(), dz.data_ptr(),
+                                          dgamma.data_ptr(), dbeta.data_ptr(), B * L, D, stream), "ms_ln_gate_bwd")
+            rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), xc.device,
+                              lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream))
+            _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
+        dxc = du4.sum(dim=0).view_as(xc)
+        return dxc, dproj, ddelta, dA, dD, dbias, dz, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):
+    """x_proj follows the ambient autocast (bf16 under autocast, like the reference's einsum would, MedMamba.py:397);
+    dt_proj (K = R <= 24) is fp32 always (MedMamba.py:403-409)."""
     B, H, W, D = xc.shape
     N, R = d_state, dt_rank
     C = R + 2 * N
@@ -148,7 +228,28 @@ def ss2d_core(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, d_s
     with torch.autocast(device_type="cuda", enabled=False):
         dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                   # (4, M, R)
         delta = torch.bmm(dts, dt_projs_weight.float().transpose(1, 2))                     # (4, M, D)
-        As = -torch.exp(A_logs.float())                                                      # (4D, N)
-        y = _SS2DScan.apply(xc, proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D), As, Ds.float().view(-1),
-                            dt_projs_bias.float().view(-1), H, W, N, R)
+    return proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D)
+
+
+def ss2d_core_norm_gate(xc, z, mod):
+    """xc (B,H,W,D) fp32 conv output, z (B,H,W,D) gate (view of xz) -> out_norm(merge(scan)) * silu(z), (B,H,W,D) in the
+    dtype out_proj will consume (bf16 under bf16 autocast, else fp32).  `mod` is the SS2D module (parameters)."""
+    B, H, W, D = xc.shape
+    proj, delta = _projections(xc, mod.x_proj_weight, mod.dt_projs_weight, mod.d_state, mod.dt_rank)
+    out_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    with torch.autocast(device_type="cuda", enabled=False):
+        As = -torch.exp(mod.A_logs.float())
+        return _SS2DScanNormGate.apply(xc, proj, delta, As, mod.Ds.float().view(-1), mod.dt_projs_bias.float().view(-1),
+                                       z, mod.out_norm.weight, mod.out_norm.bias, mod.out_norm.eps, H, W,
+                                       mod.d_state, mod.dt_rank, out_bf16)
+
+
+def ss2d_core(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, d_state, dt_rank):
+    """xc (B,H,W,D) fp32 -> merged scan output y (B,H,W,D) fp32 (without the norm/gate tail)."""
+    B, H, W, D = xc.shape
+    proj, delta = _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank)
+    with torch.autocast(device_type="cuda", enabled=False):
+        As = -torch.exp(A_logs.float())
+        y = _SS2DScan.apply(xc, proj, delta, As, Ds.float().view(-1), dt_projs_bias.float().view(-1), H, W,
+                            d_state, dt_rank)
     return y.view(B, H, W, D)

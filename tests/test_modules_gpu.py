@@ -229,3 +229,46 @@ def test_fused_core_matches_layout_faithful_path(cfg, monkeypatch):
     assert float((dxf - dxu).abs().max()) <= 5e-4 * sc(dxu)
     for k in gu:
         assert float((gf[k] - gu[k]).abs().max()) <= 2e-3 * sc(gu[k]), k
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 96), (1, 7, 7, 768), (3, 2, 5, 70), (1, 1, 1, 130), (2, 4, 4, 1024)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_ln_gate_kernels_vs_torch(cfg, bf16):
+    """merge-sum + LayerNorm + SiLU gate (MedMamba.py:476-479) forward/backward against fp64 torch, through the C ABI."""
+    import ctypes
+    from medical_image_classification_amd import _lib
+    B, H, W, D = cfg
+    npix = B * H * W
+    gen = torch.Generator().manual_seed(D)
+    y4 = torch.randn(4, npix, D, generator=gen)
+    xz = torch.randn(npix, 2 * D, generator=gen)
+    gam = torch.randn(D, generator=gen); bet = torch.randn(D, generator=gen); g = torch.randn(npix, D, generator=gen)
+    if bf16:
+        xz = xz.bfloat16().float(); g = g.bfloat16().float()
+    y4r = y4.double().requires_grad_(); zr = xz[:, D:].double().requires_grad_()
+    gr, br = gam.double().requires_grad_(), bet.double().requires_grad_()
+    ys = ((y4r[0] + y4r[2]) + y4r[1]) + y4r[3]
+    ref = F.layer_norm(ys, (D,), gr, br, 1e-5) * F.silu(zr)
+    ref.backward(g.double())
+    d = dev()
+    dt = torch.bfloat16 if bf16 else torch.float32
+    y4d, xzd, gd = y4.to(d), xz.to(d, dt), g.to(d, dt)
+    gamd, betd = gam.to(d), bet.to(d)
+    out = torch.empty(npix, D, device=d, dtype=dt)
+    lib = _lib.lib(); st = _lib.current_stream_ptr(d)
+    zptr = xzd.data_ptr() + D * xzd.element_size()
+    _lib.check(lib.ms_ln_gate_fwd(y4d.data_ptr(), npix * D, zptr, int(bf16), 2 * D, gamd.data_ptr(), betd.data_ptr(), 1e-5,
+                                  out.data_ptr(), int(bf16), npix, D, st), "fwd")
+    tol = 2e-2 if bf16 else 1e-4
+    assert_close(out, ref.detach().numpy(), tol, tol, "out")
+    dy = torch.empty(npix, D, device=d); dz = torch.empty(npix, D, device=d, dtype=dt)
+    dgam, dbet = torch.zeros(D, device=d), torch.zeros(D, device=d)
+    _lib.check(lib.ms_ln_gate_bwd(y4d.data_ptr(), npix * D, zptr, int(bf16), 2 * D, gamd.data_ptr(), betd.data_ptr(), 1e-5,
+                                  gd.data_ptr(), int(bf16), dy.data_ptr(), dz.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+                                  npix, D, st), "bwd")
+    for k in range(4):                                   # every direction receives the same dy
+        assert_close(dy, y4r.grad[k].numpy(), 1e-3, 1e-4 * max(1.0, float(y4r.grad.abs().max())), f"dy{k}")
+    assert_close(dz, zr.grad.numpy(), tol, tol * max(1.0, float(zr.grad.abs().max())), "dz")
+    sc = max(1.0, float(gr.grad.abs().max()))
+    assert_close(dgam, gr.grad.numpy(), 1e-3, 1e-4 * sc, "dgamma")
+    assert_close(dbet, br.grad.numpy(), 1e-3, 1e-4 * sc, "dbeta")
