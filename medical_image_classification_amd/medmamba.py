@@ -23,7 +23,7 @@ import torch.utils.checkpoint as checkpoint
 from . import _lib
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate
-from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu
+from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_splitk
 
 # The channel-last fused core is the default path of SS2D.forward; MEDSCAN_FUSED=0 selects the layout-faithful path
 # (NCHW conv, materialised cross-scan/merge) that mirrors the reference's data flow op by op.
@@ -86,7 +86,7 @@ class PatchMerging2D(nn.Module):
         # order of the four taps as in the reference: (0,0), (1,0), (0,1), (1,1)
         taps = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
         x = torch.cat(taps, dim=-1).view(B, h2, w2, 4 * C)
-        return self.reduction(self.norm(x))
+        return linear_splitk(self.norm(x), self.reduction.weight)
 
 
 class SS2D(nn.Module):
@@ -204,14 +204,15 @@ class SS2D(nn.Module):
     def forward(self, x: torch.Tensor, **kwargs):
         _lib.require_cuda(x)
         B, H, W, C = x.shape
-        xz = self.in_proj(x)
+        xz = linear_splitk(x, self.in_proj.weight) if self.in_proj.bias is None else self.in_proj(x)
         x, z = xz.chunk(2, dim=-1)                                  # (B,H,W,D) each, views of xz
         default_core = getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0
         if FUSED and default_core and self.d_conv == 3 and type(self.out_norm) is nn.LayerNorm and self.d_inner <= 1024:
             # channel-last fused core: the conv reads xz in place, the scan kernel applies the 4 direction maps itself,
             # merge + out_norm + SiLU(z) gate are one kernel
             xc = dwconv3x3_silu_nhwc(x, self.conv2d.weight, self.conv2d.bias)
-            out = self.out_proj(ss2d_core_norm_gate(xc, z, self))
+            yg = ss2d_core_norm_gate(xc, z, self)
+            out = linear_splitk(yg, self.out_proj.weight) if self.out_proj.bias is None else self.out_proj(yg)
             return out if self.dropout is None else self.dropout(out)
         if FUSED and default_core and self.d_conv == 3:
             xc = dwconv3x3_silu_nhwc(x, self.conv2d.weight, self.conv2d.bias)

@@ -224,10 +224,11 @@ def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):
     N, R = d_state, dt_rank
     C = R + 2 * N
     M = B * H * W
-    proj = torch.mm(xc.view(M, D), x_proj_weight.view(4 * C, D).t()).float()                # (M, 4C)
+    from .ss2d_ops import dt_proj_splitk, linear_splitk
+    proj = linear_splitk(xc.view(M, D), x_proj_weight.view(4 * C, D)).float()               # (M, 4C)
     with torch.autocast(device_type="cuda", enabled=False):
         dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                   # (4, M, R)
-        delta = torch.bmm(dts, dt_projs_weight.float().transpose(1, 2))                     # (4, M, D)
+        delta = dt_proj_splitk(dts, dt_projs_weight.float())                                # (4, M, D)
     return proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D)
 
 

@@ -117,3 +117,83 @@ def cross_merge(ys, H, W):
 def dwconv3x3_silu(x, weight, bias):
     """SiLU(depthwise conv3x3(x) + bias), NCHW (MedMamba.py:285-294,473)."""
     return _DWConvSiLU.apply(x, weight, bias)
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x @ W^T for token matrices with a huge row count M = B*H*W and small feature dims (the in/out/x projections
+    of SS2D: M = 200 704, K/N = 48..192 at stage 0).  Forward and dX are ordinary GEMMs; the weight gradient
+    dW = dY^T @ X has an (N x K) output of a few tiles and a reduction over M, which the BLAS heuristics run on 3-12
+    workgroups.  Here the reduction is split into S slices evaluated as one batched GEMM (S*tiles workgroups) and summed
+    in fp32 -- split-K by construction."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ac = torch.is_autocast_enabled()
+        dt = torch.get_autocast_dtype("cuda") if ac else None
+        xm = x.reshape(-1, x.shape[-1])
+        if ac:
+            xm, w = xm.to(dt), weight.to(dt)
+        else:
+            w = weight
+        with torch.autocast(device_type="cuda", enabled=False):
+            y = torch.mm(xm, w.t())
+        ctx.save_for_backward(xm, w)
+        ctx.xshape, ctx.wdtype, ctx.xdtype = x.shape, weight.dtype, x.dtype
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, w = ctx.saved_tensors
+        M, K = xm.shape
+        N = w.shape[0]
+        dym = dy.reshape(M, N).to(xm.dtype)
+        with torch.autocast(device_type="cuda", enabled=False):
+            dx = torch.mm(dym, w) if ctx.needs_input_grad[0] else None
+            S = 1
+            for cand in (128, 64, 32, 16, 8, 4, 2):
+                if M % cand == 0 and M // cand >= 1024:
+                    S = cand
+                    break
+            if S > 1:
+                part = torch.bmm(dym.view(S, M // S, N).transpose(1, 2), xm.view(S, M // S, K))    # (S, N, K)
+                dw = part.float().sum(dim=0)
+            else:
+                dw = torch.mm(dym.t(), xm).float()
+        return (dx.view(ctx.xshape).to(ctx.xdtype) if dx is not None else None), dw.to(ctx.wdtype)
+
+
+def linear_splitk(x, weight):
+    """F.linear(x, weight) (no bias) with a split-K weight gradient; falls back to F.linear for small row counts."""
+    if x.is_cuda and x.numel() // x.shape[-1] >= 8192:
+        return _LinearSplitK.apply(x, weight)
+    return torch.nn.functional.linear(x, weight)
+
+
+class _DtProjSplitK(torch.autograd.Function):
+    """delta[k] = dts[k] @ Wdt[k]^T for the 4 directions (MedMamba.py:400), fp32: dts (4,M,R), Wdt (4,D,R) -> (4,M,D).
+    The weight gradient dWdt[k] = ddelta[k]^T @ dts[k] reduces over M = B*H*W with a (D x R) output (R = 3..24): split
+    into S slices per direction, one batched GEMM, fp32 sum."""
+
+    @staticmethod
+    def forward(ctx, dts, wdt):
+        ctx.save_for_backward(dts, wdt)
+        return torch.bmm(dts, wdt.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, dd):
+        dts, wdt = ctx.saved_tensors
+        K4, M, R = dts.shape
+        D = wdt.shape[1]
+        dd = dd.contiguous()
+        ddts = torch.bmm(dd, wdt) if ctx.needs_input_grad[0] else None            # (4, M, R)
+        S = 1
+        for cand in (64, 32, 16, 8, 4, 2):
+            if M % cand == 0 and M // cand >= 1024:
+                S = cand
+                break
+        part = torch.bmm(dd.view(K4 * S, M // S, D).transpose(1, 2), dts.view(K4 * S, M // S, R))   # (4S, D, R)
+        return ddts, part.view(K4, S, D, R).sum(dim=1)
+
+
+def dt_proj_splitk(dts, wdt):
+    return _DtProjSplitK.apply(dts, wdt)
