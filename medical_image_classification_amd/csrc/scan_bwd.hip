@@ -70,8 +70,10 @@ struct ChannelReduce {
 
 constexpr int next_pow2(int v) { int r = 1; while (r < v) r *= 2; return r; }
 
+constexpr int kWPB = 4;      // waves per workgroup in the backward: independent except for the per-chunk dB/dC combine
+
 template <int NPL, int CW, int MODE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kWPB)
 scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4, NV = next_pow2(4 * NPL);
     using Tile = TileIO<MODE, CW>;
@@ -79,17 +81,21 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     using CR = ChannelReduce<NV, CW>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     const MsScanParams &p = q.f;
-    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];
-    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
-    __shared__ __attribute__((aligned(16))) float sdB[NP * kRowPitch];   // this chunk's dB / dC of the wave's 16 channels
-    __shared__ __attribute__((aligned(16))) float sdC[NP * kRowPitch];
-    __shared__ float su[kTile];       // u tile      -> du tile
-    __shared__ float sdl[kTile];      // delta' tile
-    __shared__ float sg_[kTile];      // dout tile   -> ddelta tile
-    __shared__ float sck[NB * NPL * 64];   // h at the start of each 4-position batch
-    __shared__ float sbias[kCW];
-    __shared__ int spos[2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float sB_[kWPB][NP * kRowPitch];
+    __shared__ __attribute__((aligned(16))) float sC_[kWPB][NP * kRowPitch];
+    __shared__ __attribute__((aligned(16))) float sdB_[kWPB][NP * kRowPitch];   // this chunk's dB / dC of each wave's channels
+    __shared__ __attribute__((aligned(16))) float sdC_[kWPB][NP * kRowPitch];
+    __shared__ float su_[kWPB][kTile];       // u tile      -> du tile
+    __shared__ float sdl_[kWPB][kTile];      // delta' tile
+    __shared__ float sg__[kWPB][kTile];      // dout tile   -> ddelta tile
+    __shared__ float sck_[kWPB][NB * NPL * 64];   // h at the start of each 4-position batch
+    __shared__ float sbias_[kWPB][kCW];
+    __shared__ int spos_[kWPB][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *sB = sB_[wv], *sC = sC_[wv], *sdB = sdB_[wv], *sdC = sdC_[wv];
+    float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sck = sck_[wv], *sbias = sbias_[wv];
+    int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
 
     const int N = p.dstate, L = p.seqlen;
@@ -99,17 +105,23 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     // instead of making all eight fetch the same rows (speed only, never correctness).
     int pair, cb;
     {
+        const int ncg = (ncb + kWPB - 1) / kWPB;            // workgroups per (batch, group)
         const int npairs = p.batch * p.n_groups, bid = blockIdx.x;
-        const int full = (npairs / 8) * 8 * ncb;            // pairs that form complete groups of 8
-        if (bid < full) { pair = (bid / (8 * ncb)) * 8 + bid % 8; cb = (bid / 8) % ncb; }
-        else            { pair = (npairs / 8) * 8 + (bid - full) / ncb; cb = (bid - full) % ncb; }
+        const int full = (npairs / 8) * 8 * ncg;            // pairs that form complete groups of 8
+        int cg;
+        if (bid < full) { pair = (bid / (8 * ncg)) * 8 + bid % 8; cg = (bid / 8) % ncg; }
+        else            { pair = (npairs / 8) * 8 + (bid - full) / ncg; cg = (bid - full) % ncg; }
+        cb = cg * kWPB + wv;
     }
     const int g = pair % p.n_groups;
     const int b = pair / p.n_groups;
-    const int nvalid = min(kCW, dpg - cb * kCW);
+    // a wave past the last channel block (ncb not a multiple of kWPB) computes on zeros and only joins the barriers
+    const bool wave_idle = cb >= ncb;
+    if (wave_idle) cb = ncb - 1;
+    const int nvalid = wave_idle ? 0 : min(kCW, dpg - cb * kCW);
     const int d0 = g * dpg + cb * kCW;
     const bool active = c < nvalid;
-    const int d = d0 + (active ? c : nvalid - 1);
+    const int d = d0 + (active ? c : max(nvalid, 1) - 1);
 
     float An[NPL], A2[NPL], dhc[NPL], dAacc[NPL];
 #pragma unroll
@@ -122,7 +134,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;
     const float fD = sg == 0 ? 1.0f : 0.0f;            // dD is accumulated once per channel, by group 0
     float dDacc = 0.0f, dbacc = 0.0f;
-    if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, nvalid - 1)] : 0.0f;
+    if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, max(nvalid, 1) - 1)] : 0.0f;
 
     const int c0w = cb * kCW;                                   // first channel of this wave inside its group
     const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0w * p.u_d_stride;
@@ -271,12 +283,40 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         tile.store(su, dub, q.du_d_stride, q.du_l_stride, l0, pm, nvalid, len);
         tile.store(sg_, ddb, q.ddelta_d_stride, q.ddelta_l_stride, l0, pm, nvalid, len);
         // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
-        if (MODE == kModeSS2D && dCb == dBb + N && q.dB_l_stride == q.dC_l_stride) {
-            rows.flush_add_pair(sdB, sdC, dBb, q.dB_l_stride, pm, N, len);
-        } else {
-            rows.flush_add(sdB, dBb, q.dB_dstate_stride, q.dB_l_stride, l0, pm, N, len);
-            rows.flush_add(sdC, dCb, q.dC_dstate_stride, q.dC_l_stride, l0, pm, N, len);
+        // combine the dB / dC tiles of the workgroup's waves (same batch and group, adjacent channel blocks) and add the
+        // sums to global memory: kWPB x fewer atomics than one flush per wave.  The only two barriers of the chunk.
+        __syncthreads();
+        {
+            constexpr int NT = 64 * kWPB, TOT = 2 * NP * kCL;
+            for (int idx = threadIdx.x; idx < TOT; idx += NT) {
+                const int isC = idx / (NP * kCL), rem = idx % (NP * kCL);
+                int n, l;
+                if (MODE == kModeSS2D) {            // (n, tensor) fastest: dB|dC of a pixel are adjacent in the projection row
+                    const int t = idx % (2 * NP); l = idx / (2 * NP); n = t % NP;
+                    if ((t >= NP) != (isC != 0)) { /* remap: idx enumerates (l, tensor, n) in SS2D mode */ }
+                    const int tc = t >= NP;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < kWPB; ++w) v += (tc ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
+                    if (n < N && l < len) {
+                        float *base = tc ? dCb : dBb;
+                        const int64_t sn = tc ? q.dC_dstate_stride : q.dB_dstate_stride, sl = tc ? q.dC_l_stride : q.dB_l_stride;
+                        atomicAdd(base + pm.tab[l] * sl + n * sn, v);
+                    }
+                    continue;
+                }
+                l = rem % kCL; n = rem / kCL;
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kWPB; ++w) v += (isC ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
+                if (n < N && l < len) {
+                    float *base = isC ? dCb : dBb;
+                    const int64_t sn = isC ? q.dC_dstate_stride : q.dB_dstate_stride, sl = isC ? q.dC_l_stride : q.dB_l_stride;
+                    atomicAdd(base + (int64_t)(l0 + l) * sl + n * sn, v);
+                }
+            }
         }
+        __syncthreads();
         wave_sync();
     }
 
@@ -302,15 +342,15 @@ static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream
     const MsScanParams &p = q.f;
     const int dpg = p.dim / p.n_groups;
     const int ncb = (dpg + CW - 1) / CW;
-    const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncb));
+    const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ((ncb + kWPB - 1) / kWPB)));
     const bool lcontig = p.u_l_stride == 1 && p.delta_l_stride == 1 && q.dout_l_stride == 1 &&
                          q.du_l_stride == 1 && q.ddelta_l_stride == 1;
     const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && q.dout_d_stride == 1 &&
                          q.du_d_stride == 1 && q.ddelta_d_stride == 1;
     switch (pick_mode(lcontig, dcontig, p.map_h)) {
-        case kModeSS2D: hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64), 0, stream, q, n_chunks, ncb); break;
-        case kModeCL:   hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64), 0, stream, q, n_chunks, ncb); break;
-        default:        hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64), 0, stream, q, n_chunks, ncb); break;
+        case kModeSS2D: hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
+        case kModeCL:   hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
+        default:        hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
     }
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
