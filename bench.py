@@ -189,8 +189,10 @@ def main():
         achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+        if os.path.exists(tp):            # PMC passes are tied to the workload they were taken on
+            tj = json.load(open(tp))
+            if tj.get("workload") == f"{args.variant}-{args.res}-bs{args.batch_size}":
+                traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 4),

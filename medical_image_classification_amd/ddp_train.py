@@ -27,8 +27,9 @@ def setup_distributed(backend=None):
         local_rank = int(os.environ.get("LOCAL_RANK", rank))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        backend = os.environ.get("MEDSCAN_DIST_BACKEND") or backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local_rank %= max(1, torch.cuda.device_count())       # (rehearsals with more ranks than visible GPUs)
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         return True, rank, world, local_rank

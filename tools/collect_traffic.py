@@ -22,5 +22,6 @@ for k in ("scan_fwd", "scan_bwd"):
         res[k] = {"hbm_bytes_per_launch": int(f + w), "fetch_bytes_per_launch_corrected": int(f),
                   "write_bytes_per_launch": int(w), "launches_sampled": fe[k][1],
                   "note": "average over the launches of one bench.py run (4 stage shapes, MedMamba-T bs 64); FETCH_SIZE x2 per guide"}
+res["workload"] = sys.argv[4] if len(sys.argv) > 4 else "T-224-bs64"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
