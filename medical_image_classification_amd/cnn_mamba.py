@@ -1,0 +1,352 @@
+"""SSD (Mamba-2) variant of the model -- module surface of the reference's CNN_Mamba.py, the file its train.py /
+ddp_train.py import as shipped (`from CNN_Mamba import VSSM as medmamba`, train.py:11): ConvTConvPW :43,
+SS2D_with_SSD :322 (named MedSSD in CrossMamba/CrossMamba_fusion_2b2.py:390), SS_Conv_SSD :583, VSSLayer :622,
+VSSM :752.  Same constructor arguments, forward signatures and state_dict keys.
+
+The arithmetic of this path lives in a third-party package that is NOT in the reference tree:
+`mamba_ssm==2.2.2` (README.md:7) -- `ops.triton.ssd_combined.mamba_chunk_scan_combined` and
+`ops.triton.layernorm_gated.RMSNorm`.  They are restated here from the call-site contract (CNN_Mamba.py:506-537,
+428-431,555-556) and the published recurrence
+    h_t = exp(dt_t*A_h) h_{t-1} + dt_t * B_t (x) x_t ,   y_t = C_t . h_t + D_h x_t ,   dt = softplus(dt + dt_bias)
+PARITY UNPINNED against the Triton kernels (nothing in the reference pins results at this boundary);
+the restatement is cross-checked against the pinned S6 oracle by expanding scalar-A heads to diagonal A
+(tests/test_ssd_cpu.py, tests/test_ssd_gpu.py).
+
+Mapping onto the gfx950 S6 kernels: a head of `headdim` channels = `headdim` channels sharing A and dt; the state axis
+(ngroups*d_state, = 4*d_state in SS2D_with_SSD where the four directions' B/C are concatenated, CNN_Mamba.py:506-519)
+is split into slices of <= 16 states whose outputs add (the recurrence is independent per state), one
+`selective_scan_fn` call per slice.  No CPU fallback.
+"""
+import math
+from functools import partial
+from typing import Callable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from . import _lib
+from .medmamba import CONV_CHANNELS_LAST, DropPath, PatchEmbed2D, PatchMerging2D, channel_shuffle
+from .selective_scan_interface import selective_scan_fn
+from .ss2d_fused import dwconv3x3_silu_nhwc
+
+_STATE_SLICE = 16      # states per kernel call (the backward kernels are built for dstate <= 16)
+
+
+def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt_bias=None, initial_states=None,
+                              seq_idx=None, cu_seqlens=None, dt_softplus=False, dt_limit=(0.0, float("inf")),
+                              return_final_states=False):
+    """Call-site contract of mamba_ssm 2.2.2's SSD scan as used at CNN_Mamba.py:523-537.
+    x (b,l,h,p), dt (b,l,h), A (h), B/C (b,l,g,n), D (h) or (h,p), dt_bias (h) -> y (b,l,h,p) in x's dtype.
+    `chunk_size` is an algorithmic detail of the Triton kernels, not semantics: ignored."""
+    if z is not None or initial_states is not None or seq_idx is not None or cu_seqlens is not None or return_final_states:
+        raise RuntimeError("mamba_chunk_scan_combined: z / initial_states / seq_idx / cu_seqlens / final states are not "
+                           "used by this repository's models and are not built")
+    if dt_limit != (0.0, float("inf")):
+        raise RuntimeError("mamba_chunk_scan_combined: dt_limit is not built")
+    _lib.require_cuda(x, dt, A, B, C)
+    b, l, h, p = x.shape
+    g, n = B.shape[2], B.shape[3]
+    if h % g != 0:
+        raise RuntimeError("mamba_chunk_scan_combined: nheads must be a multiple of ngroups")
+    dim = h * p
+    u = x.float().reshape(b, l, dim).transpose(1, 2)                       # (b, dim, l), channel-last strides
+    delta = dt.float().unsqueeze(-1).expand(b, l, h, p).reshape(b, l, dim).transpose(1, 2)
+    A_full = A.float().view(h, 1, 1).expand(h, p, 1).reshape(dim, 1)      # same A for every channel and state of a head
+    if D is not None:
+        Dc = D.float()
+        Dc = Dc.reshape(dim) if Dc.dim() == 2 else Dc.view(h, 1).expand(h, p).reshape(dim)
+    else:
+        Dc = None
+    bias = dt_bias.float().view(h, 1).expand(h, p).reshape(dim).contiguous() if dt_bias is not None else None
+    Bt = B.float().permute(0, 2, 3, 1)                                      # (b, g, n, l)
+    Ct = C.float().permute(0, 2, 3, 1)
+    y = None
+    for s0 in range(0, n, _STATE_SLICE):
+        s1 = min(n, s0 + _STATE_SLICE)
+        yi = selective_scan_fn(u, delta, A_full.expand(dim, s1 - s0).contiguous(), Bt[:, :, s0:s1], Ct[:, :, s0:s1],
+                               Dc if s0 == 0 else None, None, bias, dt_softplus)
+        y = yi if y is None else y + yi
+    return y.transpose(1, 2).reshape(b, l, h, p).to(x.dtype)
+
+
+class RMSNormGated(nn.Module):
+    """mamba_ssm.ops.triton.layernorm_gated.RMSNorm as constructed at CNN_Mamba.py:430-431:
+    norm_before_gate=False -> y = rmsnorm(x * silu(z)) * weight, one group, no bias."""
+
+    def __init__(self, hidden_size, eps=1e-5, group_size=None, norm_before_gate=True, device=None, dtype=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+        self.register_parameter("bias", None)
+        self.group_size = group_size
+        self.norm_before_gate = norm_before_gate
+
+    def forward(self, x, z=None):
+        dt = x.dtype
+        x = x.float()
+        if z is not None and not self.norm_before_gate:
+            x = x * F.silu(z.float())
+        gs = self.group_size or x.shape[-1]
+        xg = x.view(*x.shape[:-1], x.shape[-1] // gs, gs)
+        xg = xg * torch.rsqrt(xg.pow(2).mean(-1, keepdim=True) + self.eps)
+        out = xg.view_as(x) * self.weight.float()
+        if z is not None and self.norm_before_gate:
+            out = out * F.silu(z.float())
+        return out.to(dt)
+
+
+class ConvTConvPW(nn.Module):
+    """Image-space stem of CNN_Mamba.VSSM (CNN_Mamba.py:43-94): BN -> conv k1 -> BN (same module) -> ReLU -> conv k2 ->
+    + identity -> pointwise conv.  (The reference calls torch.flip twice and discards the result, :84,89: a no-op.)"""
+
+    def __init__(self, in_channels, kernel1=3, kernel2=5, kernel3=1, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.in_channels, self.k1, self.k2, self.k3 = in_channels, kernel1, kernel2, kernel3
+        self.act = nn.ReLU()
+        self.bn = nn.BatchNorm2d(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, in_channels, kernel_size=self.k1, stride=1, padding=(self.k1 - 1) // 2)
+        self.conv2 = nn.Conv2d(in_channels, in_channels, kernel_size=self.k2, stride=1, padding=(self.k2 - 1) // 2)
+        self.PW_conv = nn.Conv2d(in_channels, in_channels, kernel_size=self.k3)
+
+    def forward(self, x):
+        identity = x
+        x = self.conv1(self.bn(x))
+        x = self.conv2(self.act(self.bn(x)))
+        return self.PW_conv(x + identity)
+
+
+def _scan_orders(H, W, device):
+    """idx[k, l] = pixel visited at step l by direction k (CNN_Mamba.py:494-498 = MedMamba.py:393-395) and its inverse."""
+    L = H * W
+    l = torch.arange(L, device=device)
+    col = (l % H) * W + l // H
+    idx = torch.stack([l, col, L - 1 - l, col.flip(0)])
+    inv = torch.empty_like(idx)
+    inv.scatter_(1, idx, l.expand(4, L))
+    return idx, inv
+
+
+class SS2D_with_SSD(nn.Module):
+    """CNN_Mamba.py:322-564.  state_dict: in_proj.weight (2*d_inner + 2*G*N + nheads, d_model), conv2d.{weight
+    (d_ssm+2GN+nheads,1,3,3), bias}, dt_bias (4,nheads), A_logs (4*nheads), Ds (4*nheads | 4*d_ssm), norm.weight (d_ssm),
+    out_proj.weight (d_model, d_inner)."""
+
+    def __init__(self, d_model, d_state=128, d_conv=3, expand=2, headdim=64, d_ssm=None, ngroups=1,
+                 A_init_range=(1, 16), D_has_hdim=False, rmsnorm=True, norm_before_gate=False, dt_rank="auto",
+                 dt_min=0.001, dt_max=0.1, dt_init="random", dt_scale=1.0, dt_init_floor=1e-4,
+                 dt_limit=(0.0, float("inf")), dropout=0., conv_bias=True, bias=False, chunk_size=256,
+                 use_mem_eff_path=True, layer_idx=None, process_group=None, sequence_parallel=True, device=None,
+                 dtype=None, **kwargs):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__()
+        if process_group is not None:
+            raise RuntimeError("tensor-parallel SS2D_with_SSD is dead code in the reference (no caller passes "
+                               "process_group, CNN_Mamba.py:595) and is not built")
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.process_group, self.sequence_parallel, self.world_size, self.local_rank = None, sequence_parallel, 1, 0
+        self.d_inner = int(self.expand * self.d_model)
+        self.headdim = headdim
+        self.d_ssm = self.d_inner if d_ssm is None else d_ssm
+        self.ngroups = ngroups
+        assert self.d_ssm % self.headdim == 0
+        self.nheads = self.d_ssm // self.headdim
+        self.D_has_hdim, self.rmsnorm, self.norm_before_gate = D_has_hdim, rmsnorm, norm_before_gate
+        self.dt_limit, self.chunk_size, self.use_mem_eff_path, self.layer_idx = dt_limit, chunk_size, use_mem_eff_path, layer_idx
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+
+        d_in_proj = 2 * self.d_inner + 2 * self.ngroups * self.d_state + self.nheads          # [z, x, B, C, dt]
+        self.in_proj = nn.Linear(self.d_model, d_in_proj, bias=bias, **fk)
+        conv_dim = self.d_ssm + 2 * self.ngroups * self.d_state + self.nheads
+        self.conv2d = nn.Conv2d(conv_dim, conv_dim, groups=conv_dim, bias=conv_bias, kernel_size=d_conv,
+                                padding=(d_conv - 1) // 2, **fk)
+        self.act = nn.SiLU()
+        dt = torch.exp(torch.rand(self.nheads, **fk) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min))
+        dt = torch.clamp(dt, min=dt_init_floor)
+        inv_dt = dt + torch.log(-torch.expm1(-dt))
+        self.dt_bias = nn.Parameter(torch.stack([inv_dt] * 4, dim=0))                          # (4, nheads)
+        self.dt_bias._no_weight_decay = True
+        self.A_logs = self.A_log_init(A_init_range, self.nheads, dtype, copies=4)              # (4*nheads)
+        self.Ds = self.D_init(self.d_ssm, self.D_has_hdim, self.nheads, copies=4)              # (4*nheads) | (4*d_ssm)
+        if self.rmsnorm:
+            self.norm = RMSNormGated(self.d_ssm, eps=1e-5, norm_before_gate=self.norm_before_gate,
+                                     group_size=self.d_ssm // ngroups, **fk)
+        self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **fk)
+        self.dropout = nn.Dropout(dropout) if dropout > 0. else None
+
+    @staticmethod
+    def A_log_init(A_init_range, nheads, dtype, copies=1, device=None, merge=True):
+        assert A_init_range[0] > 0 and A_init_range[1] >= A_init_range[0]
+        A_log = torch.log(torch.empty(nheads, dtype=torch.float32, device=device).uniform_(*A_init_range)).to(dtype=dtype)
+        if copies > 1:
+            A_log = A_log.unsqueeze(0).repeat(copies, 1)
+            if merge:
+                A_log = A_log.flatten(0, 1)
+        A_log = nn.Parameter(A_log)
+        A_log._no_weight_decay = True
+        return A_log
+
+    @staticmethod
+    def D_init(d_ssm, D_has_hdim, nheads, copies=1, device=None, merge=True):
+        D = torch.ones(d_ssm if D_has_hdim else nheads, device=device)
+        if copies > 1:
+            D = D.unsqueeze(0).repeat(copies, 1)
+            if merge:
+                D = D.flatten(0, 1)
+        D = nn.Parameter(D)
+        D._no_weight_decay = True
+        return D
+
+    def forward(self, u: torch.Tensor, seqlen=None, seq_idx=None, cu_seqlens=None):
+        _lib.require_cuda(u)
+        B, H, W, C = u.shape
+        L, K = H * W, 4
+        GN = self.ngroups * self.d_state
+        zxbcdt = self.in_proj(u)
+        d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * GN - self.nheads) // 2
+        z0, x0, z, xBCdt = torch.split(zxbcdt, [d_mlp, d_mlp, self.d_ssm, self.d_ssm + 2 * GN + self.nheads], dim=-1)
+        # depthwise conv + SiLU over the whole [x | B | C | dt] stack (dt goes through the conv too, CNN_Mamba.py:490-491),
+        # channel-last, reading zxbcdt in place
+        if self.d_conv == 3:
+            xc = dwconv3x3_silu_nhwc(xBCdt, self.conv2d.weight, self.conv2d.bias)              # (B,H,W,conv_dim) fp32
+        else:
+            xc = self.act(self.conv2d(xBCdt.permute(0, 3, 1, 2))).permute(0, 2, 3, 1).float()
+        conv_dim = xc.shape[-1]
+        # 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
+        idx, inv = _scan_orders(H, W, u.device)
+        xs4 = xc.reshape(B, L, conv_dim)[:, idx.reshape(-1)].view(B, K, L, conv_dim).transpose(1, 2)
+        xs, Bs, Cs, dts = torch.split(xs4, [self.d_ssm, GN, GN, self.nheads], dim=-1)
+        # layouts of CNN_Mamba.py:506-519: heads = (direction, head); B/C = the four directions' states concatenated
+        xs = xs.reshape(B, L, K * self.nheads, self.headdim)
+        dts = dts.reshape(B, L, K * self.nheads)
+        Bs = Bs.reshape(B, L, self.ngroups, -1)          # flat (k, g, n) order regrouped as "(g n)", as :517-519 does
+        Cs = Cs.reshape(B, L, self.ngroups, -1)
+        As = -torch.exp(self.A_logs.float())
+        Ds = self.Ds.view(-1, self.headdim) if self.D_has_hdim else self.Ds
+        y = mamba_chunk_scan_combined(xs.float(), dts.float(), As, Bs.float(), Cs.float(), chunk_size=self.chunk_size,
+                                      D=Ds, z=None, dt_bias=self.dt_bias.view(-1), dt_softplus=True)
+        y = y.reshape(B, L, K, self.d_ssm)
+        assert y.dtype == torch.float
+        # cross-merge (CNN_Mamba.py:542-552): bring every direction back to pixel order and add, ((y1+y2)+y3)+y4
+        yk = [y[:, inv[k], k] for k in range(K)]
+        out = ((yk[0] + yk[2]) + yk[1]) + yk[3]
+        out = out.view(B, H, W, -1)
+        if self.rmsnorm:
+            out = self.norm(out, z)
+        if d_mlp > 0:
+            out = torch.cat([F.silu(z0) * x0, out], dim=-1)
+        out_data = self.out_proj(out)
+        if self.dropout is not None:
+            out_data = self.dropout(out_data)
+        return out_data
+
+
+class SS_Conv_SSD(nn.Module):
+    """CNN_Mamba.py:583-619: same two-branch block as SS_Conv_SSM with the SSD mixer on the right half."""
+
+    def __init__(self, hidden_dim: int = 0, drop_path: float = 0,
+                 norm_layer: Callable[..., torch.nn.Module] = partial(nn.LayerNorm, eps=1e-6),
+                 attn_drop_rate: float = 0, d_state: int = 64, **kwargs):
+        super().__init__()
+        half = hidden_dim // 2
+        self.ln_1 = norm_layer(half)
+        self.self_attention = SS2D_with_SSD(d_model=half, dropout=attn_drop_rate, d_state=d_state, **kwargs)
+        self.drop_path = DropPath(drop_path)
+        self.conv33conv33conv11 = nn.Sequential(
+            nn.BatchNorm2d(half), nn.Conv2d(half, half, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(half), nn.ReLU(), nn.Conv2d(half, half, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(half), nn.ReLU(), nn.Conv2d(half, half, kernel_size=1, stride=1), nn.ReLU())
+
+    def forward(self, input: torch.Tensor):
+        left, right = input.chunk(2, dim=-1)
+        x = self.drop_path(self.self_attention(self.ln_1(right)))
+        if CONV_CHANNELS_LAST and left.is_cuda:
+            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+            left = left.permute(0, 2, 3, 1)
+        else:
+            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+        return channel_shuffle(torch.cat((left, x), dim=-1), groups=2) + input
+
+
+class VSSLayer(nn.Module):
+    """CNN_Mamba.py:622-685."""
+
+    def __init__(self, dim, depth, attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None,
+                 use_checkpoint=False, d_state=64, **kwargs):
+        super().__init__()
+        self.dim, self.use_checkpoint = dim, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SS_Conv_SSD(hidden_dim=dim, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                        norm_layer=norm_layer, attn_drop_rate=attn_drop, d_state=d_state) for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
+        return x if self.downsample is None else self.downsample(x)
+
+
+class VSSM(nn.Module):
+    """CNN_Mamba.py:752-851: defaults dims [128,256,512,1024], d_state 16 (-> SSD state 4*16 = 64), ConvTConvPW stem."""
+
+    def __init__(self, patch_size=4, in_chans=3, num_classes=1000, depths=[2, 2, 4, 2], depths_decoder=[2, 9, 2, 2],
+                 dims=[128, 256, 512, 1024], dims_decoder=[1024, 512, 256, 128], d_state=16, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, patch_norm=True,
+                 use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        if isinstance(dims, int):
+            dims = [int(dims * 2 ** i) for i in range(self.num_layers)]
+        self.embed_dim, self.num_features, self.dims = dims[0], dims[-1], dims
+        self.patch_embed = PatchEmbed2D(patch_size=patch_size, in_chans=in_chans, embed_dim=self.embed_dim,
+                                        norm_layer=norm_layer if patch_norm else None)
+        self.ape = False
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [r.item() for r in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(VSSLayer(
+                dim=dims[i], depth=depths[i], d_state=math.ceil(dims[0] / 6) if d_state is None else d_state,
+                drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                norm_layer=norm_layer, downsample=PatchMerging2D if (i < self.num_layers - 1) else None,
+                use_checkpoint=use_checkpoint))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.conv_T_conv = ConvTConvPW(in_channels=in_chans)
+        self.apply(self._init_weights)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _init_weights(self, m: nn.Module):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"relative_position_bias_table"}
+
+    def forward_backbone(self, x):
+        x = self.pos_drop(self.patch_embed(x))
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def forward(self, x):
+        x = self.forward_backbone(self.conv_T_conv(x))
+        x = self.avgpool(x.permute(0, 3, 1, 2))
+        return self.head(torch.flatten(x, start_dim=1))
+
+
+MedSSD = SS2D_with_SSD      # the name CrossMamba/CrossMamba_fusion_2b2.py:390 gives the same class

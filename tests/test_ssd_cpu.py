@@ -1,0 +1,141 @@
+"""CPU checks of the SSD (Mamba-2) widening: the sequential restatement oracle/ssd_oracle.py against
+the PINNED S6 oracle by the scalar-A -> diagonal-A expansion, the state_dict surface of
+CNN_Mamba.py's classes (keys/shapes read off CNN_Mamba.py:403-436,622-800 -- the file cannot be imported here, its
+mamba_ssm/triton dependencies are absent), and the no-CPU-fallback rule.  PARITY UNPINNED vs the Triton kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scan_oracle as so
+from oracle import ssd_oracle
+
+
+@pytest.mark.parametrize("cfg", [(2, 11, 3, 4, 1, 8), (1, 37, 8, 8, 1, 64), (2, 20, 4, 2, 2, 5)])
+@pytest.mark.parametrize("hdim_D", [False, True])
+def test_ssd_restatement_equals_s6_oracle_by_expansion(cfg, hdim_D):
+    b, l, h, p, g, n = cfg
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(b, l, h, p, generator=gen)
+    dt = torch.randn(b, l, h, generator=gen)
+    A = -torch.rand(h, generator=gen) * 4 - 0.2
+    B = torch.randn(b, l, g, n, generator=gen)
+    C = torch.randn(b, l, g, n, generator=gen)
+    D = torch.randn(h, p, generator=gen) if hdim_D else torch.randn(h, generator=gen)
+    bias = torch.randn(h, generator=gen)
+    y = ssd_oracle.ssd_scan_ref(x, dt, A, B, C, D=D, dt_bias=bias, dt_softplus=True)
+    # S6 view: channel d = (head, p); A[d, :] = A[head]; delta[d] = dt[head]; B/C groups shared by h/g heads
+    dim = h * p
+    u = x.reshape(b, l, dim).permute(0, 2, 1).contiguous().numpy()
+    delta = dt.repeat_interleave(p, dim=2).permute(0, 2, 1).contiguous().numpy()
+    A6 = A.repeat_interleave(p)[:, None].expand(dim, n).contiguous().numpy()
+    D6 = (D.reshape(dim) if hdim_D else D.repeat_interleave(p)).numpy()
+    b6 = bias.repeat_interleave(p).numpy()
+    out, _ = so.scan_fwd(u, delta, A6, B.permute(0, 2, 3, 1).contiguous().numpy(),
+                         C.permute(0, 2, 3, 1).contiguous().numpy(), D6, None, b6, True)
+    want = torch.from_numpy(out).permute(0, 2, 1).reshape(b, l, h, p).numpy()
+    np.testing.assert_allclose(y.numpy(), want, rtol=2e-4, atol=2e-4 * float(np.abs(want).max()))
+
+
+def test_scan_orders_are_the_reference_cross_scan():
+    from medical_image_classification_amd.cnn_mamba import _scan_orders
+    for H, W in [(3, 5), (4, 4), (7, 2), (1, 1)]:
+        idx, inv = _scan_orders(H, W, torch.device("cpu"))
+        x = torch.arange(H * W, dtype=torch.float32).view(1, 1, H, W)
+        xs = so.cross_scan(x.numpy())[0, :, 0]                       # (4, L): pixel visited at step l
+        assert np.array_equal(idx.numpy(), xs.astype(np.int64))
+        for k in range(4):
+            assert np.array_equal(idx[k][inv[k]].numpy(), np.arange(H * W))
+
+
+def expected_ssd_keys(prefix, d_model, d_state, headdim=64, expand=2, ngroups=1):
+    d_inner = expand * d_model
+    nheads = d_inner // headdim
+    conv_dim = d_inner + 2 * ngroups * d_state + nheads
+    return {
+        prefix + "dt_bias": (4, nheads), prefix + "A_logs": (4 * nheads,), prefix + "Ds": (4 * nheads,),
+        prefix + "in_proj.weight": (2 * d_inner + 2 * ngroups * d_state + nheads, d_model),
+        prefix + "conv2d.weight": (conv_dim, 1, 3, 3), prefix + "conv2d.bias": (conv_dim,),
+        prefix + "norm.weight": (d_inner,), prefix + "out_proj.weight": (d_model, d_inner),
+    }
+
+
+def test_ss2d_with_ssd_state_dict_surface():
+    from medical_image_classification_amd.cnn_mamba import MedSSD, SS2D_with_SSD
+    assert MedSSD is SS2D_with_SSD
+    m = SS2D_with_SSD(d_model=64, d_state=16)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == expected_ssd_keys("", 64, 16)
+    assert m.nheads == 2 and m.d_ssm == 128
+    for name in ("dt_bias", "A_logs", "Ds"):
+        assert getattr(getattr(m, name), "_no_weight_decay", False)
+    # init ranges of CNN_Mamba.py:403-428: A in [1,16], D = 1, softplus(dt_bias) in [1e-3, 1e-1]
+    A = torch.exp(m.A_logs.detach())
+    assert float(A.min()) >= 1 - 1e-5 and float(A.max()) <= 16 + 1e-4
+    assert torch.equal(m.Ds, torch.ones(8))
+    dt = torch.nn.functional.softplus(m.dt_bias.detach())
+    assert float(dt.min()) >= 1e-4 - 1e-7 and float(dt.max()) <= 0.1 + 1e-6
+    assert torch.equal(m.dt_bias[0], m.dt_bias[3])
+
+
+def test_ssd_vssm_state_dict_surface():
+    from medical_image_classification_amd.cnn_mamba import VSSM
+    net = VSSM(depths=[1, 2], dims=[128, 256], num_classes=5)
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    want = {}
+    want.update({"patch_embed.proj.weight": (128, 3, 4, 4), "patch_embed.proj.bias": (128,),
+                 "patch_embed.norm.weight": (128,), "patch_embed.norm.bias": (128,)})
+    for li, (dim, depth) in enumerate([(128, 1), (256, 2)]):
+        half = dim // 2
+        for bi in range(depth):
+            p = f"layers.{li}.blocks.{bi}."
+            want.update({p + "ln_1.weight": (half,), p + "ln_1.bias": (half,)})
+            want.update(expected_ssd_keys(p + "self_attention.", half, 16))
+            for ci, kind in enumerate(["bn", "conv3", "bn", None, "conv3", "bn", None, "conv1", None]):
+                q = p + f"conv33conv33conv11.{ci}."
+                if kind == "bn":
+                    want.update({q + "weight": (half,), q + "bias": (half,), q + "running_mean": (half,),
+                                 q + "running_var": (half,), q + "num_batches_tracked": ()})
+                elif kind == "conv3":
+                    want.update({q + "weight": (half, half, 3, 3), q + "bias": (half,)})
+                elif kind == "conv1":
+                    want.update({q + "weight": (half, half, 1, 1), q + "bias": (half,)})
+    want.update({"layers.0.downsample.reduction.weight": (256, 512), "layers.0.downsample.norm.weight": (512,),
+                 "layers.0.downsample.norm.bias": (512,)})
+    want.update({"head.weight": (5, 256), "head.bias": (5,)})
+    want.update({"conv_T_conv.bn.weight": (3,), "conv_T_conv.bn.bias": (3,), "conv_T_conv.bn.running_mean": (3,),
+                 "conv_T_conv.bn.running_var": (3,), "conv_T_conv.bn.num_batches_tracked": (),
+                 "conv_T_conv.conv1.weight": (3, 3, 3, 3), "conv_T_conv.conv1.bias": (3,),
+                 "conv_T_conv.conv2.weight": (3, 3, 5, 5), "conv_T_conv.conv2.bias": (3,),
+                 "conv_T_conv.PW_conv.weight": (3, 3, 1, 1), "conv_T_conv.PW_conv.bias": (3,)})
+    assert got == want
+    # defaults of CNN_Mamba.py:753-756
+    import inspect
+    sig = inspect.signature(VSSM.__init__).parameters
+    assert sig["dims"].default == [128, 256, 512, 1024] and sig["d_state"].default == 16
+    assert sig["depths"].default == [2, 2, 4, 2] and sig["num_classes"].default == 1000
+
+
+def test_ssd_module_oracle_runs_and_product_refuses_cpu():
+    from medical_image_classification_amd.cnn_mamba import SS2D_with_SSD, mamba_chunk_scan_combined
+    torch.manual_seed(0)
+    m = SS2D_with_SSD(d_model=32, d_state=4, headdim=16)
+    u = torch.randn(2, 3, 5, 32)
+    y = ssd_oracle.ss2d_ssd_forward_oracle(m, u)
+    assert y.shape == (2, 3, 5, 32) and torch.isfinite(y).all()
+    with pytest.raises(RuntimeError):
+        m(u)                                                     # product path: HIP only, no CPU fallback
+    with pytest.raises(RuntimeError):
+        mamba_chunk_scan_combined(torch.randn(1, 4, 2, 8), torch.randn(1, 4, 2), -torch.ones(2),
+                                  torch.randn(1, 4, 1, 4), torch.randn(1, 4, 1, 4))
+
+
+def test_rmsnorm_gated_matches_restatement():
+    from medical_image_classification_amd.cnn_mamba import RMSNormGated
+    torch.manual_seed(1)
+    for nbg in (False, True):
+        n = RMSNormGated(48, eps=1e-5, norm_before_gate=nbg, group_size=48)
+        with torch.no_grad():
+            n.weight.copy_(torch.randn(48))
+        x, z = torch.randn(3, 7, 48), torch.randn(3, 7, 48)
+        want = ssd_oracle.rmsnorm_gated_ref(x, z, n.weight, 1e-5, nbg)
+        np.testing.assert_allclose(n(x, z).detach().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)

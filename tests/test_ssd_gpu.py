@@ -1,0 +1,124 @@
+"""GPU parity of the SSD (Mamba-2) widening, through the C-ABI scan kernels, against oracle/ssd_oracle.py (sequential
+float64 restatement, itself checked against the pinned S6 oracle in tests/test_ssd_cpu.py).  PARITY UNPINNED against the
+reference's Triton dependency (mamba_ssm 2.2.2, absent from the tree).  Tolerance: 1e-3 relative to the tensor's max
+(north_star's fp32 bound)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ssd_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def close(got, want, tol, msg):
+    want = want.detach().float().cpu().numpy()
+    np.testing.assert_allclose(got.detach().float().cpu().numpy(), want, rtol=tol,
+                               atol=max(1e-6, tol * float(np.abs(want).max())), err_msg=msg)
+
+
+@pytest.mark.parametrize("cfg", [(2, 30, 8, 64, 1, 64), (1, 49, 4, 16, 1, 16), (2, 65, 6, 8, 2, 24), (1, 7, 2, 64, 1, 5)])
+@pytest.mark.parametrize("hdim_D", [False, True])
+def test_chunk_scan_combined_vs_restatement(cfg, hdim_D):
+    from medical_image_classification_amd.cnn_mamba import mamba_chunk_scan_combined
+    b, l, h, p, g, n = cfg
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=gen)
+    x, dt, B, C = mk(b, l, h, p), mk(b, l, h), mk(b, l, g, n), mk(b, l, g, n)
+    A = -torch.rand(h, generator=gen) * 4 - 0.2
+    D = mk(h, p) if hdim_D else mk(h)
+    bias = mk(h)
+    gy = mk(b, l, h, p)
+    cpu = [t.clone().requires_grad_() for t in (x, dt, A, B, C, D, bias)]
+    gpu = [t.to(dev()).requires_grad_() for t in (x, dt, A, B, C, D, bias)]
+    yr = ssd_oracle.ssd_scan_ref(cpu[0], cpu[1], cpu[2], cpu[3], cpu[4], D=cpu[5], dt_bias=cpu[6], dt_softplus=True)
+    yd = mamba_chunk_scan_combined(gpu[0], gpu[1], gpu[2], gpu[3], gpu[4], chunk_size=256, D=gpu[5], z=None,
+                                   dt_bias=gpu[6], dt_softplus=True)
+    assert yd.shape == (b, l, h, p) and yd.dtype == torch.float32
+    yr.backward(gy); yd.backward(gy.to(dev()))
+    close(yd, yr, 1e-3, "y")
+    for name, a, r in zip(("dx", "ddt", "dA", "dB", "dC", "dD", "dbias"), gpu, cpu):
+        close(a.grad, r.grad, 2e-3, name)
+
+
+def test_chunk_scan_combined_no_softplus_no_bias_no_D():
+    from medical_image_classification_amd.cnn_mamba import mamba_chunk_scan_combined
+    gen = torch.Generator().manual_seed(5)
+    x, dt = torch.randn(1, 20, 2, 8, generator=gen), torch.rand(1, 20, 2, generator=gen) * 0.5
+    A, B, C = -torch.ones(2), torch.randn(1, 20, 1, 8, generator=gen), torch.randn(1, 20, 1, 8, generator=gen)
+    yr = ssd_oracle.ssd_scan_ref(x, dt, A, B, C)
+    yd = mamba_chunk_scan_combined(*(t.to(dev()) for t in (x, dt, A, B, C)), chunk_size=64)
+    close(yd, yr, 1e-3, "y")
+    with pytest.raises(RuntimeError):
+        mamba_chunk_scan_combined(*(t.to(dev()) for t in (x, dt, A, B, C)), chunk_size=64, z=x.to(dev()))
+
+
+@pytest.mark.parametrize("cfg", [(64, 16, 64, 6, 5, False), (32, 4, 16, 3, 7, True), (64, 16, 64, 1, 1, False)])
+def test_ss2d_with_ssd_vs_restatement(cfg):
+    from medical_image_classification_amd.cnn_mamba import SS2D_with_SSD
+    d_model, d_state, headdim, H, W, hdim_D = cfg
+    torch.manual_seed(2)
+    m = SS2D_with_SSD(d_model=d_model, d_state=d_state, headdim=headdim, D_has_hdim=hdim_D)
+    with torch.no_grad():                                        # break the symmetry of the four copies / ones
+        m.Ds.add_(torch.randn_like(m.Ds) * 0.3); m.A_logs.add_(torch.randn_like(m.A_logs) * 0.3)
+        m.dt_bias.add_(torch.randn_like(m.dt_bias)); m.norm.weight.add_(torch.randn_like(m.norm.weight) * 0.2)
+    ref = SS2D_with_SSD(d_model=d_model, d_state=d_state, headdim=headdim, D_has_hdim=hdim_D)
+    ref.load_state_dict(m.state_dict())
+    m.to(dev())
+    u = torch.randn(2, H, W, d_model)
+    g = torch.randn(2, H, W, d_model)
+    ur = u.clone().requires_grad_(); ud = u.to(dev()).requires_grad_()
+    yr = ssd_oracle.ss2d_ssd_forward_oracle(ref, ur)
+    yd = m(ud)
+    yr.backward(g); yd.backward(g.to(dev()))
+    close(yd, yr, 1e-3, "y")
+    close(ud.grad, ur.grad, 2e-3, "du")
+    pr = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        close(p.grad, pr[k].grad, 2e-3, k)
+
+
+def test_ssd_vssm_train_step_vs_cpu_restatement():
+    from medical_image_classification_amd.cnn_mamba import VSSM
+    torch.manual_seed(4)
+    net = VSSM(depths=[1, 1], dims=[128, 256], num_classes=3, drop_path_rate=0.0)
+    ref = VSSM(depths=[1, 1], dims=[128, 256], num_classes=3, drop_path_rate=0.0)
+    ref.load_state_dict(net.state_dict())
+    ssd_oracle.install_ssd(ref)
+    net.to(dev()).train(); ref.train()
+    x = torch.randn(2, 3, 32, 32)
+    t = torch.tensor([0, 2])
+    lr_ = torch.nn.functional.cross_entropy(ref(x), t)
+    ld_ = torch.nn.functional.cross_entropy(net(x.to(dev())), t.to(dev()))
+    lr_.backward(); ld_.backward()
+    assert abs(float(ld_) - float(lr_)) <= 1e-3 * max(1.0, abs(float(lr_)))
+    pr = dict(ref.named_parameters())
+    for k, p in net.named_parameters():
+        if "self_attention" in k or k.startswith("head"):
+            r = pr[k].grad.numpy()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=1e-2, atol=max(1e-5, 5e-3 * float(np.abs(r).max())),
+                                       err_msg=k)
+
+
+def test_ssd_vssm_default_config_autocast_step_runs():
+    """CNN_Mamba.VSSM as train.py:58 builds it (dims 128..1024, d_state 16 -> SSD state 64), bf16 autocast, 64x64 input."""
+    from medical_image_classification_amd.cnn_mamba import VSSM
+    torch.manual_seed(0)
+    net = VSSM(num_classes=7).to(dev()).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    x = torch.randn(2, 3, 64, 64, device=dev())
+    t = torch.tensor([1, 5], device=dev())
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(net(x), t)
+        loss.backward(); opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
