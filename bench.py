@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=64, help="per GPU (BASELINE.json: bs=64)")
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--num-classes", type=int, default=8)
-    ap.add_argument("--variant", default="T", choices=["T", "B"])
+    ap.add_argument("--variant", default="T", choices=["T", "B", "SSD"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
                     help="autocast dtype of the dense GEMM/conv ops; the scan is fp32 in both (MedMamba.py:403-409)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,6 +63,11 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+WORKLOADS = {"T": "depths/dims/d_state of BASELINE.json configs[1]",
+             "B": "depths [2,2,12,2], dims [128..1024]: BASELINE.json configs[2]",
+             "SSD": "CNN_Mamba.VSSM defaults, the SSD/Mamba-2 variant the reference's train.py imports"}
 
 
 def cpu_baseline_worker(args):
@@ -204,13 +209,17 @@ def main():
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype + "+f32scan" if args.dtype == "bf16" else "f32",
                "data": "synthetic",
-               "config": {"workload": f"MedMamba-{args.variant} (depths/dims/d_state of BASELINE.json configs[1]) full "
+               "config": {"workload": f"MedMamba-{args.variant} ({WORKLOADS[args.variant]}) full "
                                       f"training step fwd+bwd+Adam, {args.batch_size} x 3x{args.res}x{args.res} per GPU, "
                                       f"{args.num_classes} classes, random-init weights",
                           "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                           "loss": round(final_loss, 4)},
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.variant == "SSD":
+            out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port",
+                                   "sample": "not timed for the non-headline SSD variant (its restatement is a float64 "
+                                             "Python loop over L, sized for parity tests only)"}
+        elif world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline leg ...")
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -9,76 +9,29 @@
 //   dA_n  += dh_l*delta'_l*(a_l*h_{l-1}) ;  dB += dh_l*delta'_l*u_l ;  dC += g_l*h_l ;  dD += g_l*u_l
 //   ddelta = ddl * softplus'(delta+bias),  softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
 //
-// One wave = 16 channels x all states, lane (sg, c) owns NPL states of channel c (scan_common.h).
+// One wave = CW channels x all states, lane (sg, c) owns NPL <= 2 states of channel c (scan_common.h).
 // Chunks of MS_SCAN_CHUNK positions are visited last->first (the next one is prefetched into registers).
-// Per chunk: (1) a forward sweep from the saved state x[b,c-1] stores h at the start of every 4-position
-// batch in LDS; (2) a reverse sweep recomputes (a, h) of one batch into a register window and runs the
-// adjoint recurrence backwards over it.  Sums over the state axis (du, ddelta) are permlane
-// reduce-scatters; the per-(l,n) dB/dC contributions are summed over the wave's 16 channels by a DPP
-// reduce-scatter into a per-chunk LDS tile, flushed with 128-byte-row global atomics.  No barriers.
+// Per chunk, fully unrolled: (1) a forward sweep from the saved state x[b,c-1] keeps the decay a = exp2(delta'*A)
+// of all 32 positions in registers (so every exp2 is evaluated once per backward) and h at the start of every
+// 4-position batch; (2) a reverse sweep rebuilds h of one batch from its checkpoint (mul + fma) and runs the
+// adjoint recurrence backwards over it.  Sums over the state axis (du, ddelta) are permlane reduce-scatters;
+// the per-(l,n) dB/dC contributions are summed over the wave's CW channels by a transpose through a wave-private
+// LDS tile (conflict-free b32 writes, b128 row reads), then over the workgroup's 4 waves, then added to global
+// memory with atomics.
 #include "scan_common.h"
 
 namespace ms {
 
-// Reduce NV (a power of two, zero-padded by the caller) values over the CW channel lanes of a wave
-// (lane bits 0 .. log2(CW)-1, all inside one DPP row).  Levels at distance CW/2 ... 1; while more than one
-// value is live a level halves the set (reduce-scatter), afterwards it is a plain butterfly add.
-// `owner_index(cbits, r)` tells which input index ended up in slot r of the lane with channel bits cbits.
-template <int NV, int CW>
-struct ChannelReduce {
-    static constexpr int kOut = NV >= CW ? NV / CW : 1;
-    template <int S, int CNT>
-    __device__ static __forceinline__ void level(float (&v)[NV], int lane) {
-        if constexpr (CNT > 1) {
-#pragma unroll
-            for (int i = 0; i < CNT / 2; ++i) v[i] = xchg_add<S>(v[i], v[i + CNT / 2], lane);
-        } else {
-            constexpr int CTRL = S == 8 ? 0x128 : S == 4 ? 0x12C : S == 2 ? 0x4E : 0xB1;
-            constexpr int CTRL2 = S == 4 ? 0x124 : CTRL;
-            const float up = dpp_mov<CTRL>(v[0]), dn = dpp_mov<CTRL2>(v[0]);
-            v[0] += (lane & S) ? dn : up;
-        }
-    }
-    __device__ static __forceinline__ void run(float (&v)[NV], int lane) {
-        if constexpr (CW == 16) {
-            level<8, NV>(v, lane);
-            level<4, (NV >= 2 ? NV / 2 : 1)>(v, lane);
-            level<2, (NV >= 4 ? NV / 4 : 1)>(v, lane);
-            level<1, (NV >= 8 ? NV / 8 : 1)>(v, lane);
-        } else {
-            level<4, NV>(v, lane);
-            level<2, (NV >= 2 ? NV / 2 : 1)>(v, lane);
-            level<1, (NV >= 4 ? NV / 4 : 1)>(v, lane);
-        }
-    }
-    __device__ static __forceinline__ int owner_index(int cbits, int r) {
-        int idx = r, cnt = NV;
-        constexpr int LV = CW == 16 ? 4 : 3;
-#pragma unroll
-        for (int k = 0; k < LV; ++k) {
-            const int bit = (cbits >> (LV - 1 - k)) & 1;
-            if (cnt > 1) { idx += bit * (cnt / 2); cnt /= 2; }
-        }
-        return idx;
-    }
-    // lanes that own distinct results (when NV < CW several lanes hold the same total)
-    __device__ static __forceinline__ bool is_owner(int cbits) {
-        if (NV >= CW) return true;
-        return (cbits & (CW / NV - 1)) == 0;        // the low channel bits only replicate
-    }
-};
-
-constexpr int next_pow2(int v) { int r = 1; while (r < v) r *= 2; return r; }
-
 constexpr int kWPB = 4;      // waves per workgroup in the backward: independent except for the per-chunk dB/dC combine
 
 template <int NPL, int CW, int MODE>
-__global__ void __launch_bounds__(64 * kWPB)
+__global__ void __launch_bounds__(64 * kWPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
-    constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4, NV = next_pow2(4 * NPL);
+    constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4;
+    constexpr int kRows = 4 * NPL * SG, kTP = CW + 4;      // transpose tile: rows x (CW + pad) floats, 16-byte aligned rows
+    static_assert(kRows <= 64, "one lane per (position, state) of a batch");
     using Tile = TileIO<MODE, CW>;
     using Rows = RowIO<MODE, NP>;
-    using CR = ChannelReduce<NV, CW>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     const MsScanParams &p = q.f;
     __shared__ __attribute__((aligned(16))) float sB_[kWPB][NP * kRowPitch];
@@ -88,15 +41,18 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     __shared__ float su_[kWPB][kTile];       // u tile      -> du tile
     __shared__ float sdl_[kWPB][kTile];      // delta' tile
     __shared__ float sg__[kWPB][kTile];      // dout tile   -> ddelta tile
-    __shared__ float sck_[kWPB][NB * NPL * 64];   // h at the start of each 4-position batch
+    __shared__ __attribute__((aligned(16))) float sTB_[kWPB][kRows * kTP];   // channel-sum transpose tiles (one batch)
+    __shared__ __attribute__((aligned(16))) float sTC_[kWPB][kRows * kTP];
     __shared__ float sbias_[kWPB][kCW];
     __shared__ int spos_[kWPB][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *sB = sB_[wv], *sC = sC_[wv], *sdB = sdB_[wv], *sdC = sdC_[wv];
-    float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sck = sck_[wv], *sbias = sbias_[wv];
+    float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sTB = sTB_[wv], *sTC = sTC_[wv], *sbias = sbias_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
+    // transpose-reduce ownership: lane rr sums row rr = (j*NPL + i)*SG + sg' -> position lb + j, state sg'*NPL + i
+    const int t_out = ((lane % SG) * NPL + (lane / SG) % NPL) * kRowPitch + lane / (NPL * SG);
 
     const int N = p.dstate, L = p.seqlen;
     const int dpg = p.dim / p.n_groups;
@@ -131,9 +87,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         A2[i] = An[i] * kLog2e;
         dhc[i] = 0.0f; dAacc[i] = 0.0f;
     }
-    const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;
-    const float fD = sg == 0 ? 1.0f : 0.0f;            // dD is accumulated once per channel, by group 0
-    float dDacc = 0.0f, dbacc = 0.0f;
+    const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;     // D*g enters du once per channel, through group 0
     if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, max(nvalid, 1) - 1)] : 0.0f;
 
     const int c0w = cb * kCW;                                   // first channel of this wave inside its group
@@ -152,46 +106,79 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float *dCb = q.dC + b * q.dC_batch_stride + g * q.dC_group_stride;
     const bool softplus = p.delta_softplus != 0;
 
+    // 32-bit copies of the strides the chunk loop needs (one SGPR each instead of slices of the 16-dword argument
+    // tuples); channel-last and SS2D modes have unit channel / state strides (validated on the host)
+    constexpr bool kGen = MODE == kModeBDL;
+    const int u_sd = kGen ? (int)p.u_d_stride : 1, u_sl = (int)p.u_l_stride;
+    const int dl_sd = kGen ? (int)p.delta_d_stride : 1, dl_sl = (int)p.delta_l_stride;
+    const int g_sd = kGen ? (int)q.dout_d_stride : 1, g_sl = (int)q.dout_l_stride;
+    const int du_sd = kGen ? (int)q.du_d_stride : 1, du_sl = (int)q.du_l_stride;
+    const int dd_sd = kGen ? (int)q.ddelta_d_stride : 1, dd_sl = (int)q.ddelta_l_stride;
+    constexpr bool kRowN = MODE == kModeSS2D;
+    const int B_sn = kRowN ? 1 : (int)p.B_dstate_stride, B_sl = (int)p.B_l_stride;
+    const int C_sn = kRowN ? 1 : (int)p.C_dstate_stride, C_sl = (int)p.C_l_stride;
+    const int dB_sn = kRowN ? 1 : (int)q.dB_dstate_stride, dB_sl = (int)q.dB_l_stride;
+    const int dC_sn = kRowN ? 1 : (int)q.dC_dstate_stride, dC_sl = (int)q.dC_l_stride;
+
     const Tile tile(lane);
     const Rows rows(lane);
     const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
     float ru[Tile::NE], rd[Tile::NE], rg[Tile::NE], rB[Rows::NE], rC[Rows::NE];
+    // dD = sum g*u and ddelta_bias = sum ddelta are accumulated by the lane that stages / stores the element
+    // (Tile::NE elements per chunk) instead of inside the sweeps; reduced over the wave at the end
+    float dDk[Tile::NA], dbk[Tile::NA];
+#pragma unroll
+    for (int k = 0; k < Tile::NA; ++k) { dDk[k] = 0.0f; dbk[k] = 0.0f; }
+    float rx[NPL];          // saved state at the start of the prefetched chunk (x[b, ch-1]); zero for the first chunk
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
-        tile.fetch(ru, ub, p.u_d_stride, p.u_l_stride, l0, pm, nvalid, len);
-        tile.fetch(rd, db, p.delta_d_stride, p.delta_l_stride, l0, pm, nvalid, len);
-        tile.fetch(rg, gb, q.dout_d_stride, q.dout_l_stride, l0, pm, nvalid, len);
-        rows.fetch(rB, Bb, p.B_dstate_stride, p.B_l_stride, l0, pm, N, len);
-        rows.fetch(rC, Cb, p.C_dstate_stride, p.C_l_stride, l0, pm, N, len);
+        // the state load goes out with (and is waited for with) the tile loads: a load consumed inside the sweeps would
+        // put an s_waitcnt vmcnt(0) there and expose the whole prefetch
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int n = min(sg * NPL + i, N - 1);
+            // single-chunk sequences have no saved states (x may be null): read a dummy valid word instead of branching
+            const float *xs = n_chunks > 1 ? p.x + (((int64_t)b * n_chunks + max(ch - 1, 0)) * N + n) * p.dim + d : p.A;
+            rx[i] = *xs;
+        }
+        tile.fetch(ru, ub, u_sd, u_sl, l0, pm, nvalid, len);
+        tile.fetch(rd, db, dl_sd, dl_sl, l0, pm, nvalid, len);
+        tile.fetch(rg, gb, g_sd, g_sl, l0, pm, nvalid, len);
+        rows.fetch(rB, Bb, B_sn, B_sl, l0, pm, N, len);
+        rows.fetch(rC, Cb, C_sn, C_sl, l0, pm, N, len);
     };
     fetch(n_chunks - 1);
     wave_sync();                                           // sbias visible
 
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        tile.put(su, ru);
+        tile.put(su, ru, nvalid, len);
         tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
-        tile.put(sg_, rg);
-        rows.put(sB, rB);
-        rows.put(sC, rC);
+        tile.put(sg_, rg, nvalid, len);
+#pragma unroll
+        for (int k = 0; k < Tile::NE; ++k) dDk[Tile::ak(k)] = fmaf(rg[k], ru[k], dDk[Tile::ak(k)]);       // out-of-range elements are zero
+        rows.put(sB, rB, N, len);
+        rows.put(sC, rC, N, len);
         float h[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const int n = sg * NPL + i;
-            h[i] = (ch > 0 && n < N) ? p.x[(((int64_t)b * n_chunks + (ch - 1)) * N + n) * p.dim + d] : 0.0f;
+            h[i] = (ch > 0 && n < N) ? rx[i] : 0.0f;
         }
         wave_sync();
         if (ch > 0) fetch(ch - 1);                         // lands while this chunk is computed
 
-        // ---- forward sweep: h at the start of every 4-position batch -> LDS ---------------------------
-#pragma unroll 1
+        // ---- forward sweep: the decay a of EVERY position stays in registers (each exp2 is evaluated once per
+        //      backward), h only at the start of every 4-position batch ------------------------------------
+        float av[kCL][NPL], ck[NB][NPL];
+#pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int lb = kb * 4;
             float Bv[NPL][4];
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
-                sck[(kb * NPL + i) * 64 + lane] = h[i];
+                ck[kb][i] = h[i];
                 row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv[i]);
             }
 #pragma unroll
@@ -199,23 +186,24 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 const float dl_ = sdl[(lb + j) * kPitch + c];
                 const float du_ = dl_ * su[(lb + j) * kPitch + c];
 #pragma unroll
-                for (int i = 0; i < NPL; ++i)
-                    h[i] = fmaf(exp2_fast(dl_ * A2[i]), h[i], du_ * Bv[i][j]);
+                for (int i = 0; i < NPL; ++i) {
+                    av[lb + j][i] = exp2_fast(dl_ * A2[i]);
+                    h[i] = fmaf(av[lb + j][i], h[i], du_ * Bv[i][j]);
+                }
             }
         }
-        // ---- reverse sweep: per batch, recompute (a, h) into a 4-position register window, then run the
-        //      adjoint recurrence backwards over the window --------------------------------------------
-#pragma unroll 1
+        // ---- reverse sweep: per batch, rebuild h of its 4 positions from the checkpoint and the stored a
+        //      (mul + fma, no exp), then run the adjoint recurrence backwards over the window ---------------
+#pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            float Bv[NPL][4], Cv[NPL][4], hs[NPL];
+            float Bv[NPL][4], Cv[NPL][4];
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
-                hs[i] = sck[(kb * NPL + i) * 64 + lane];
                 row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv[i]);
                 row4(sC + (sg * NPL + i) * kRowPitch, lb, Cv[i]);
             }
-            float dl_[4], uu[4], gg[4], av[4][NPL], hv[4][NPL];
+            float dl_[4], uu[4], gg[4], bu[4][NPL], hv[4][NPL];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 dl_[j] = sdl[(lb + j) * kPitch + c];
@@ -224,64 +212,65 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 const float du_ = dl_[j] * uu[j];
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
-                    av[j][i] = exp2_fast(dl_[j] * A2[i]);
-                    hv[j][i] = fmaf(av[j][i], j > 0 ? hv[j > 0 ? j - 1 : 0][i] : hs[i], du_ * Bv[i][j]);
+                    bu[j][i] = du_ * Bv[i][j];
+                    hv[j][i] = fmaf(av[lb + j][i], j > 0 ? hv[j > 0 ? j - 1 : 0][i] : ck[kb][i], bu[j][i]);
                 }
             }
-            float duv[4], ddv[4], vB[NV], vC[NV];
-#pragma unroll
-            for (int r = 4 * NPL; r < NV; ++r) { vB[r] = 0.0f; vC[r] = 0.0f; }
+            float duv[4], ddv[4], vB[4 * NPL], vC[4 * NPL];
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
                 const float du_ = dl_[j] * uu[j];
-                float du_l = Dv * gg[j], dd_l = 0.0f;
-                dDacc = fmaf(fD * gg[j], uu[j], dDacc);
+                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
-                    const float hprev = j > 0 ? hv[j > 0 ? j - 1 : 0][i] : hs[i];
                     const float dhn = fmaf(Cv[i][j], gg[j], dhc[i]);
-                    const float w = av[j][i] * hprev;
-                    const float t = dhn * Bv[i][j];
-                    du_l = fmaf(t, dl_[j], du_l);
-                    dd_l = fmaf(t, uu[j], dd_l);
+                    const float w = hv[j][i] - bu[j][i];             // = a_j * h_{j-1}
+                    s1 = fmaf(dhn, Bv[i][j], s1);
                     const float qv = dhn * w;
-                    dd_l = fmaf(qv, An[i], dd_l);
+                    s2 = fmaf(qv, An[i], s2);
                     dAacc[i] = fmaf(qv, dl_[j], dAacc[i]);
                     vB[j * NPL + i] = dhn * du_;
                     vC[j * NPL + i] = gg[j] * hv[j][i];
-                    dhc[i] = av[j][i] * dhn;
+                    dhc[i] = av[lb + j][i] * dhn;
                 }
-                duv[j] = du_l; ddv[j] = dd_l;
+                duv[j] = fmaf(s1, dl_[j], Dv * gg[j]);               // du_l  = D g + delta' sum_n dh B
+                ddv[j] = fmaf(s1, uu[j], s2);                         // ddl_l = u sum_n dh B + sum_n dh A (a h_prev)
             }
             // sums over the state axis: group sg receives the totals of position lb + sg
             const float du_t = sum_groups_scatter4<CW>(duv, lane);
-            float dd_t = sum_groups_scatter4<CW>(ddv, lane);
+            const float dd_t = sum_groups_scatter4<CW>(ddv, lane);
             if (is_group_owner<CW>(lane)) {
                 const int lo = lb + group_slot<CW>(lane);
-                if (softplus) dd_t *= sigmoid_from_softplus(sdl[lo * kPitch + c]);
-                dbacc += dd_t;
                 su[lo * kPitch + c] = du_t;                // in place: this batch's u / dout are in registers
-                sg_[lo * kPitch + c] = dd_t;
+                sg_[lo * kPitch + c] = dd_t;               // d delta' ; the softplus derivative is applied by the store
             }
-            // sums over the wave's 16 channels of the per-(position, state) dB / dC terms
-            CR::run(vB, lane);
-            CR::run(vC, lane);
-            if (CR::is_owner(c)) {
+            // sums over the wave's CW channels of the per-(position, state) dB / dC terms: transpose through LDS.
+            // Lane (sg, c) writes its 4*NPL values into rows (r*SG + sg), column c (64 consecutive floats per r);
+            // lane rr then reads row rr (CW consecutive floats), adds them and owns (position, state) = row_of(rr).
+            wave_sync();
 #pragma unroll
-                for (int r = 0; r < CR::kOut; ++r) {
-                    const int idx = CR::owner_index(c, r);
-                    const int j = idx / NPL, i = idx % NPL;
-                    if (4 * NPL == NV || idx < 4 * NPL) {
-                        sdB[(sg * NPL + i) * kRowPitch + lb + j] = vB[r];
-                        sdC[(sg * NPL + i) * kRowPitch + lb + j] = vC[r];
-                    }
+            for (int r = 0; r < 4 * NPL; ++r) {
+                sTB[(r * SG + sg) * kTP + c] = vB[r];
+                sTC[(r * SG + sg) * kTP + c] = vC[r];
+            }
+            wave_sync();
+            if (kRows == 64 || lane < kRows) {
+                float tb = 0.0f, tc = 0.0f;
+#pragma unroll
+                for (int k4 = 0; k4 < CW / 4; ++k4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(sTB + lane * kTP + 4 * k4);
+                    const float4 y = *reinterpret_cast<const float4 *>(sTC + lane * kTP + 4 * k4);
+                    tb += (x.x + x.y) + (x.z + x.w);
+                    tc += (y.x + y.y) + (y.z + y.w);
                 }
+                sdB[t_out + lb] = tb;
+                sdC[t_out + lb] = tc;
             }
         }
         wave_sync();
         if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
-        tile.store(su, dub, q.du_d_stride, q.du_l_stride, l0, pm, nvalid, len);
-        tile.store(sg_, ddb, q.ddelta_d_stride, q.ddelta_l_stride, l0, pm, nvalid, len);
+        tile.store(su, dub, du_sd, du_sl, l0, pm, nvalid, len);
+        tile.store_ddelta(sg_, sdl, sp_mask, ddb, dd_sd, dd_sl, l0, pm, nvalid, len, dbk);
         // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
         // combine the dB / dC tiles of the workgroup's waves (same batch and group, adjacent channel blocks) and add the
         // sums to global memory: kWPB x fewer atomics than one flush per wave.  The only two barriers of the chunk.
@@ -300,8 +289,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     for (int w = 0; w < kWPB; ++w) v += (tc ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
                     if (n < N && l < len) {
                         float *base = tc ? dCb : dBb;
-                        const int64_t sn = tc ? q.dC_dstate_stride : q.dB_dstate_stride, sl = tc ? q.dC_l_stride : q.dB_l_stride;
-                        atomicAdd(base + pm.tab[l] * sl + n * sn, v);
+                        atomicAdd(base + __mul24(pm.tab[l], tc ? dC_sl : dB_sl) + n, v);
                     }
                     continue;
                 }
@@ -311,8 +299,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 for (int w = 0; w < kWPB; ++w) v += (isC ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
                 if (n < N && l < len) {
                     float *base = isC ? dCb : dBb;
-                    const int64_t sn = isC ? q.dC_dstate_stride : q.dB_dstate_stride, sl = isC ? q.dC_l_stride : q.dB_l_stride;
-                    atomicAdd(base + (int64_t)(l0 + l) * sl + n * sn, v);
+                    atomicAdd(base + (int64_t)(l0 + l) * (isC ? dC_sl : dB_sl) + n * (isC ? dC_sn : dB_sn), v);
                 }
             }
         }
@@ -326,15 +313,35 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             const int n = sg * NPL + i;
             if (n < N) atomicAdd(q.dA + (int64_t)d * N + n, dAacc[i]);
         }
-        if (q.dD != nullptr && sg == 0) atomicAdd(q.dD + d, dDacc);
-        if (q.ddelta_bias != nullptr) atomicAdd(q.ddelta_bias + d, dbacc);
+    }
+    // dD / ddelta_bias: every lane holds partial sums of the tile elements it staged / stored
+    if constexpr (Tile::LCONTIG) {            // lane = one position of channels ck(k)
+#pragma unroll
+        for (int k = 0; k < Tile::NE; ++k) {
+            float a = dDk[k], e = dbk[k];
+#pragma unroll
+            for (int m = 1; m < kCL; m *= 2) { a += __shfl_xor(a, m); e += __shfl_xor(e, m); }      // over the 32 positions
+            if ((lane & (kCL - 1)) == 0 && tile.ck(k) < nvalid) {
+                if (q.dD != nullptr) atomicAdd(q.dD + d0 + tile.ck(k), a);
+                if (q.ddelta_bias != nullptr) atomicAdd(q.ddelta_bias + d0 + tile.ck(k), e);
+            }
+        }
+    } else {                                  // lane = channel lane % CW of positions lane / CW + (64/CW) k
+        float a = dDk[0], e = dbk[0];
+#pragma unroll
+        for (int m = CW; m < 64; m *= 2) { a += __shfl_xor(a, m); e += __shfl_xor(e, m); }
+        if (lane < CW && lane < nvalid) {
+            if (q.dD != nullptr) atomicAdd(q.dD + d0 + lane, a);
+            if (q.ddelta_bias != nullptr) atomicAdd(q.ddelta_bias + d0 + lane, e);
+        }
     }
 }
 
 int validate_scan(const MsScanParams &p);
 int pick_npl(int dstate, int sg);
 bool use_cw8(const MsScanParams &p, bool backward);
-int pick_mode(bool l_contig, bool d_contig, int map_h);
+int pick_mode(bool l_contig, bool d_contig, bool small, int map_h);
+bool fits24(int64_t v);
 bool act_strides_ok(int64_t sd, int64_t sl, int seqlen);
 
 template <int NPL, int CW>
@@ -347,7 +354,11 @@ static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream
                          q.du_l_stride == 1 && q.ddelta_l_stride == 1;
     const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && q.dout_d_stride == 1 &&
                          q.du_d_stride == 1 && q.ddelta_d_stride == 1;
-    switch (pick_mode(lcontig, dcontig, p.map_h)) {
+    const bool small = fits24(p.seqlen) && fits24(p.u_l_stride) && fits24(p.delta_l_stride) && fits24(q.dout_l_stride) &&
+                       fits24(q.du_l_stride) && fits24(q.ddelta_l_stride) && fits24(p.B_l_stride) && fits24(p.C_l_stride) &&
+                       fits24(q.dB_l_stride) && fits24(q.dC_l_stride);
+    if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
+    switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
         case kModeSS2D: hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
         case kModeCL:   hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
         default:        hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
@@ -377,9 +388,7 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
     }
     switch (pick_npl(p.dstate, 4)) {
         case 1: return launch_bwd<1, 16>(q, n_chunks, stream);
-        case 2: return launch_bwd<2, 16>(q, n_chunks, stream);
-        case 3: return launch_bwd<3, 16>(q, n_chunks, stream);
-        case 4: return launch_bwd<4, 16>(q, n_chunks, stream);
+        case 2: return launch_bwd<2, 16>(q, n_chunks, stream);     // dstate 5..7 (8..16 took the 8-channel waves above)
     }
     return MS_ERR_DSTATE;       // backward is built for dstate <= 16
 }

@@ -75,11 +75,16 @@ struct PosMap {
         int t = (mode & 2) ? L - 1 - l : l;
         if (mode & 1) {
             const int w = (int)(((float)t + 0.5f) * invH);      // exact for t < 2^22
-            t = (t - w * H) * W + w;
+            t = __mul24(t - __mul24(w, H), W) + w;           // all factors < 2^22 (validated)
         }
         return t;
     }
 };
+
+// position * stride.  v_mul_lo_u32 is a quarter-rate instruction; the channel-last modes (whose sequence lengths and
+// sequence strides the host validates to be < 2^24) use the full-rate 24-bit multiply instead.
+template <bool SMALL>
+__device__ __forceinline__ int pos_times(int pos, int stride) { return SMALL ? __mul24(pos, stride) : pos * stride; }
 
 // kernel addressing modes
 constexpr int kModeBDL = 0;      // activations contiguous along L (reference (B,D,L) layout); B/C rows contiguous along L
@@ -107,33 +112,34 @@ struct TileIO {
     __device__ __forceinline__ int soff(int k) const { return l0_ * kPitch + c0_ + k * STEP * (LCONTIG ? 1 : kPitch); }
     __device__ __forceinline__ int lk(int k) const { return LCONTIG ? l0_ : l0_ + k * STEP; }
     __device__ __forceinline__ int ck(int k) const { return LCONTIG ? c0_ + k * STEP : c0_; }
-    __device__ __forceinline__ uint32_t goff(int k, int64_t sd, int64_t sl, int lbase, const PosMap &pm) const {
+    // strides are 32-bit element counts (validated on the host); channel-last modes have a unit channel stride
+    __device__ __forceinline__ uint32_t goff(int k, int sd, int sl, int lbase, const PosMap &pm) const {
         const int pos = MODE == kModeSS2D ? pm.tab[lk(k)] : lbase + lk(k);
-        return (uint32_t)(ck(k) * (int)sd + pos * (int)sl) * 4u;
+        return (uint32_t)(ck(k) * (LCONTIG ? sd : 1) + pos_times<!LCONTIG>(pos, sl)) * 4u;
     }
     __device__ __forceinline__ bool ok(int k, int nvalid, int len) const { return lk(k) < len && ck(k) < nvalid; }
-    // branch-free: out-of-range elements read the tile's first element (always valid) and are zeroed by a
-    // select, so the NE loads stay one straight-line batch instead of NE exec-masked blocks
-    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sd, int64_t sl, int lbase,
+    // branch-free and use-free: out-of-range elements read the tile's first element (always valid); NOTHING consumes the
+    // loaded registers here -- the zeroing of out-of-range elements happens in put()/put_delta() one chunk later, so no
+    // s_waitcnt can be scheduled next to the loads and the prefetch really overlaps the chunk being computed
+    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int sd, int sl, int lbase,
                                           const PosMap &pm, int nvalid, int len) const {
         const char *b = reinterpret_cast<const char *>(base);
         const uint32_t safe = first_valid(sd, sl, lbase, pm);
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const bool v = ok(k, nvalid, len);
             const uint32_t off = goff(k, sd, sl, lbase, pm);
-            const float t = *reinterpret_cast<const float *>(b + (v ? off : safe));
-            r[k] = v ? t : 0.0f;
+            r[k] = *reinterpret_cast<const float *>(b + (ok(k, nvalid, len) ? off : safe));
         }
     }
     // byte offset of an element that is always inside the tensor: (first position of the chunk, channel 0)
-    __device__ __forceinline__ uint32_t first_valid(int64_t sd, int64_t sl, int lbase, const PosMap &pm) const {
+    __device__ __forceinline__ uint32_t first_valid(int sd, int sl, int lbase, const PosMap &pm) const {
         const int pos = MODE == kModeSS2D ? pm.tab[0] : lbase;
-        return (uint32_t)(pos * (int)sl) * 4u;
+        return (uint32_t)pos_times<!LCONTIG>(pos, sl) * 4u;
     }
-    __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
+    // registers -> LDS; channels past `nvalid` and positions past `len` become zero; `r` is zeroed likewise
+    __device__ __forceinline__ void put(float *s, float (&r)[NE], int nvalid, int len) const {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) s[soff(k)] = r[k];
+        for (int k = 0; k < NE; ++k) { r[k] = ok(k, nvalid, len) ? r[k] : 0.0f; s[soff(k)] = r[k]; }
     }
     // delta tile: bias + softplus applied once per element on the way into LDS (sp_mask = all ones / zero:
     // a bit-select instead of a branch per element)
@@ -146,7 +152,23 @@ struct TileIO {
             s[soff(k)] = ok(k, nvalid, len) ? v : 0.0f;
         }
     }
-    __device__ __forceinline__ void store(const float *s, float *base, int64_t sd, int64_t sl, int lbase,
+    // per-lane accumulators over the elements a lane owns: one per channel it touches (NE in the (B,D,L) layout where
+    // the channel changes with k, a single one in the channel-last layouts)
+    static constexpr int NA = LCONTIG ? NE : 1;
+    static __device__ __forceinline__ int ak(int k) { return LCONTIG ? k : 0; }
+    // backward: ddelta = d delta' * softplus'(delta + bias), the derivative recovered from the staged delta' tile
+    // (sp_mask = 0: no softplus, factor 1); acc collects the stored values (ddelta_bias partial sums of this lane)
+    __device__ __forceinline__ void store_ddelta(const float *s, const float *sdl, unsigned sp_mask, float *base, int sd, int sl,
+                                                 int lbase, const PosMap &pm, int nvalid, int len, float (&acc)[NA]) const {
+        char *b = reinterpret_cast<char *>(base);
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const float f = bits_f((f_bits(sigmoid_from_softplus(sdl[soff(k)])) & sp_mask) | (f_bits(1.0f) & ~sp_mask));
+            const float v = s[soff(k)] * f;
+            if (ok(k, nvalid, len)) { *reinterpret_cast<float *>(b + goff(k, sd, sl, lbase, pm)) = v; acc[ak(k)] += v; }
+        }
+    }
+    __device__ __forceinline__ void store(const float *s, float *base, int sd, int sl, int lbase,
                                           const PosMap &pm, int nvalid, int len) const {
         char *b = reinterpret_cast<char *>(base);
 #pragma unroll
@@ -167,28 +189,30 @@ struct RowIO {
     __device__ __forceinline__ explicit RowIO(int lane) : lane_(lane) {}
     __device__ __forceinline__ int nk(int k) const { return NCONTIG ? (lane_ + 64 * k) % NP : lane_ / kCL + 2 * k; }
     __device__ __forceinline__ int lk(int k) const { return NCONTIG ? (lane_ + 64 * k) / NP : lane_ % kCL; }
-    __device__ __forceinline__ uint32_t goff(int k, int64_t sn, int64_t sl, int lbase, const PosMap &pm) const {
+    __device__ __forceinline__ uint32_t goff(int k, int sn, int sl, int lbase, const PosMap &pm) const {
         const int pos = NCONTIG ? pm.tab[lk(k)] : lbase + lk(k);
-        return (uint32_t)(nk(k) * (int)sn + pos * (int)sl) * 4u;
+        return (uint32_t)(nk(k) * (NCONTIG ? 1 : sn) + pos_times<MODE != kModeBDL>(pos, sl)) * 4u;
     }
-    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int64_t sn, int64_t sl, int lbase,
+    // branch-free and use-free like TileIO::fetch: every offset (including its LDS position lookup) is formed
+    // unconditionally, out-of-range elements are redirected to (state 0, first position); put() zeroes them
+    __device__ __forceinline__ void fetch(float (&r)[NE], const float *base, int sn, int sl, int lbase,
                                           const PosMap &pm, int N, int len) const {
         const char *b = reinterpret_cast<const char *>(base);
-        const uint32_t safe = (uint32_t)((NCONTIG ? pm.tab[0] : lbase) * (int)sl) * 4u;     // (state 0, first position)
+        const uint32_t safe = (uint32_t)pos_times<MODE != kModeBDL>(NCONTIG ? pm.tab[0] : lbase, sl) * 4u;
+        uint32_t off[NE];
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const bool v = nk(k) < N && lk(k) < len;
-            const float t = *reinterpret_cast<const float *>(b + (v ? goff(k, sn, sl, lbase, pm) : safe));
-            r[k] = v ? t : 0.0f;
-        }
+        for (int k = 0; k < NE; ++k) off[k] = goff(k, sn, sl, lbase, pm);
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            r[k] = *reinterpret_cast<const float *>(b + ((nk(k) < N && lk(k) < len) ? off[k] : safe));
     }
-    __device__ __forceinline__ void put(float *s, const float (&r)[NE]) const {
+    __device__ __forceinline__ void put(float *s, const float (&r)[NE], int N, int len) const {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) s[nk(k) * kRowPitch + lk(k)] = r[k];
+        for (int k = 0; k < NE; ++k) s[nk(k) * kRowPitch + lk(k)] = (nk(k) < N && lk(k) < len) ? r[k] : 0.0f;
     }
     // SS2D mode: dB and dC of one pixel are adjacent in the projection-gradient row ([.. | B(N) | C(N)]), so both staged
     // tiles are flushed together: lane idx -> (t = idx % 2NP, l = idx / 2NP), 2N*4-byte atomic segments per pixel.
-    __device__ __forceinline__ void flush_add_pair(const float *sB, const float *sC, float *baseB, int64_t sl,
+    __device__ __forceinline__ void flush_add_pair(const float *sB, const float *sC, float *baseB, int sl,
                                                    const PosMap &pm, int N, int len) const {
         char *b = reinterpret_cast<char *>(baseB);
 #pragma unroll
@@ -197,13 +221,13 @@ struct RowIO {
             const bool isC = t >= NP;
             const int n = isC ? t - NP : t;
             if (n < N && l < len) {
-                const uint32_t off = (uint32_t)(pm.tab[l] * (int)sl + n + (isC ? N : 0)) * 4u;
+                const uint32_t off = (uint32_t)(__mul24(pm.tab[l], sl) + n + (isC ? N : 0)) * 4u;
                 atomicAdd(reinterpret_cast<float *>(b + off), (isC ? sC : sB)[n * kRowPitch + l]);
             }
         }
     }
     // accumulate a staged [n][l] tile into global memory (dB / dC of the backward)
-    __device__ __forceinline__ void flush_add(const float *s, float *base, int64_t sn, int64_t sl, int lbase,
+    __device__ __forceinline__ void flush_add(const float *s, float *base, int sn, int sl, int lbase,
                                               const PosMap &pm, int N, int len) const {
         char *b = reinterpret_cast<char *>(base);
 #pragma unroll

@@ -71,6 +71,12 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = p.delta_softplus != 0;
 
+    constexpr bool kGen = MODE == kModeBDL, kRowN = MODE == kModeSS2D;      // see scan_bwd.hip: 32-bit stride copies
+    const int u_sd = kGen ? (int)p.u_d_stride : 1, u_sl = (int)p.u_l_stride;
+    const int dl_sd = kGen ? (int)p.delta_d_stride : 1, dl_sl = (int)p.delta_l_stride;
+    const int o_sd = kGen ? (int)p.out_d_stride : 1, o_sl = (int)p.out_l_stride;
+    const int B_sn = kRowN ? 1 : (int)p.B_dstate_stride, B_sl = (int)p.B_l_stride;
+    const int C_sn = kRowN ? 1 : (int)p.C_dstate_stride, C_sl = (int)p.C_l_stride;
     const Tile tile(lane);
     const Rows rows(lane);
     const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
@@ -78,20 +84,20 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
-        tile.fetch(ru, ub, p.u_d_stride, p.u_l_stride, l0, pm, nvalid, len);
-        tile.fetch(rd, db, p.delta_d_stride, p.delta_l_stride, l0, pm, nvalid, len);
-        rows.fetch(rB, Bb, p.B_dstate_stride, p.B_l_stride, l0, pm, N, len);
-        rows.fetch(rC, Cb, p.C_dstate_stride, p.C_l_stride, l0, pm, N, len);
+        tile.fetch(ru, ub, u_sd, u_sl, l0, pm, nvalid, len);
+        tile.fetch(rd, db, dl_sd, dl_sl, l0, pm, nvalid, len);
+        rows.fetch(rB, Bb, B_sn, B_sl, l0, pm, N, len);
+        rows.fetch(rC, Cb, C_sn, C_sl, l0, pm, N, len);
     };
     fetch(0);
     wave_sync();                                           // sbias visible
 
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        tile.put(su, ru);
+        tile.put(su, ru, nvalid, len);
         tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
-        rows.put(sB, rB);
-        rows.put(sC, rC);
+        rows.put(sB, rB, N, len);
+        rows.put(sC, rC, N, len);
         wave_sync();
         if (ch + 1 < n_chunks) fetch(ch + 1);              // lands while this chunk is computed
 
@@ -130,7 +136,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
         }
         wave_sync();
         if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
-        tile.store(su, ob, p.out_d_stride, p.out_l_stride, l0, pm, nvalid, len);
+        tile.store(su, ob, o_sd, o_sl, l0, pm, nvalid, len);
         wave_sync();
     }
 }
@@ -152,10 +158,12 @@ bool use_cw8(const MsScanParams &p, bool backward) {
 }
 
 // addressing mode from the strides (speed choice for plain sequences; SS2D mode when a map is given)
-int pick_mode(bool l_contig, bool d_contig, int map_h) {
+// `small`: sequence length and every sequence stride < 2^24 (the channel-last kernels multiply them with v_mul_i32_i24)
+int pick_mode(bool l_contig, bool d_contig, bool small, int map_h) {
     if (map_h > 0) return kModeSS2D;
-    return (d_contig && !l_contig) ? kModeCL : kModeBDL;
+    return (d_contig && !l_contig && small) ? kModeCL : kModeBDL;
 }
+bool fits24(int64_t v) { return v >= 0 && v < (1 << 24); }
 
 template <int NPL, int CW>
 static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
@@ -164,7 +172,10 @@ static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
     const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncb));
     const bool lcontig = p.u_l_stride == 1 && p.delta_l_stride == 1 && p.out_l_stride == 1;
     const bool dcontig = p.u_d_stride == 1 && p.delta_d_stride == 1 && p.out_d_stride == 1;
-    switch (pick_mode(lcontig, dcontig, p.map_h)) {
+    const bool small = fits24(p.seqlen) && fits24(p.u_l_stride) && fits24(p.delta_l_stride) && fits24(p.out_l_stride) &&
+                       fits24(p.B_l_stride) && fits24(p.C_l_stride);
+    if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
+    switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
         case kModeSS2D: hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64), 0, stream, p, n_chunks, ncb); break;
         case kModeCL:   hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL>), grid, dim3(64), 0, stream, p, n_chunks, ncb); break;
         default:        hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64), 0, stream, p, n_chunks, ncb); break;

@@ -66,6 +66,8 @@ def main(argv=None):
     ap.add_argument("--num-classes", type=int, default=8)
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--variant", default="T", choices=["T", "B", "SSD"],
+                    help="T/B: MedMamba.py VSSM sizes; SSD: CNN_Mamba.py VSSM (what the reference's train.py imports)")
     ap.add_argument("--save-path", default="./MedmambaNet_ddp.pth")
     ap.add_argument("--resume", default="")
     args = ap.parse_args(argv)
@@ -74,7 +76,7 @@ def main(argv=None):
     distributed, rank, world, local_rank = setup_distributed("nccl")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    net = build_model(num_classes=args.num_classes).to(device)
+    net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
     start_epoch, best_acc = 0, 0.0
     optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
     if args.resume:

@@ -19,6 +19,9 @@ def synthetic_batch(batch_size, num_classes, res=224, device="cuda", generator=N
 
 
 def build_model(num_classes=8, variant="T", **kw):
+    if variant == "SSD":                    # what the reference's train.py:11,58 builds as shipped: CNN_Mamba.VSSM
+        from .cnn_mamba import VSSM as ssd_vssm
+        return ssd_vssm(num_classes=num_classes, **kw)
     if variant == "B":                      # BASELINE.json config 3
         kw = dict(depths=[2, 2, 12, 2], dims=[128, 256, 512, 1024], **kw)
     return medmamba(num_classes=num_classes, **kw)
@@ -45,13 +48,15 @@ def main(argv=None):
     ap.add_argument("--num-classes", type=int, default=8)
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--variant", default="T", choices=["T", "B", "SSD"],
+                    help="T/B: MedMamba.py VSSM sizes; SSD: CNN_Mamba.py VSSM (what the reference's train.py imports)")
     ap.add_argument("--save-path", default="./MedmambaNet.pth")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("train.py needs an MI355X: the SS2D kernels have no CPU fallback")
     device = torch.device("cuda:0")
     print(f"using {device} device.")
-    net = build_model(num_classes=args.num_classes).to(device)
+    net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
     loss_function = nn.CrossEntropyLoss()
     optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
     gen = torch.Generator(device=device).manual_seed(0)
