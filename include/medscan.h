@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 2
+#define MEDSCAN_ABI_VERSION 3
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -151,6 +151,26 @@ int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_
 int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
                    const float *gamma, const float *beta, float eps, const void *dout, int dout_is_bf16,
                    float *dy, void *dz, float *dgamma, float *dbeta, int64_t npix, int D, void *stream);
+
+/* ---- the two-branch block around SS2D (SS_Conv_SSM, MedMamba.py:502-538) ------------------------------------
+ * ms_layernorm_fwd/bwd replace `self.ln_1(right)` on the right half of `input.chunk(2, dim=-1)` (MedMamba.py:512-515):
+ *   x      fp32 rows of D channels, unit channel stride, `x_pixel_stride` floats between pixels (the half is read in
+ *          place from the (.., 2D) block input: no contiguous copy);  out (npix, D) contiguous, fp32 or bf16.
+ *   bwd    recomputes mean/rstd from x; dx (npix, D) fp32 contiguous; dgamma/dbeta are ACCUMULATED (zero them first).
+ * ms_block_tail_fwd/bwd replace drop_path, `torch.cat((left, x), -1)`, `channel_shuffle(.., groups=2)` and
+ * `+ input` (MedMamba.py:515,534-538 and 486-499):
+ *   out[p, 2i] = left[p, i] + input[p, 2i] ;  out[p, 2i+1] = sample_scale[b(p)] * x[p, i] + input[p, 2i+1]
+ *   left, x: (npix, C/2) contiguous, fp32 or bf16; input, out: (npix, C) fp32; sample_scale: per-sample DropPath factor
+ *   (mask / keep_prob) or NULL; pixels_per_sample = H*W; C % 4 == 0.
+ *   bwd: dleft[p, i] = dout[p, 2i], dx[p, i] = sample_scale[b] * dout[p, 2i+1]; the gradient w.r.t. `input` is dout itself. */
+int ms_layernorm_fwd(const float *x, int64_t x_pixel_stride, const float *gamma, const float *beta, float eps, void *out,
+                     int out_is_bf16, int64_t npix, int D, void *stream);
+int ms_layernorm_bwd(const float *x, int64_t x_pixel_stride, const float *gamma, float eps, const void *dout, int dout_is_bf16,
+                     float *dx, float *dgamma, float *dbeta, int64_t npix, int D, void *stream);
+int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_is_bf16, const float *input,
+                      const float *sample_scale, float *out, int64_t npix, int64_t pixels_per_sample, int C, void *stream);
+int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
+                      int64_t npix, int64_t pixels_per_sample, int C, void *stream);
 
 int ms_abi_version(void);
 const char *ms_status_string(int status);

@@ -48,7 +48,9 @@ class MsScanBwdParams(ctypes.Structure):
 
 EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_cross_scan",
            "ms_cross_merge", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_dwconv3x3_silu_nhwc_fwd",
-           "ms_dwconv3x3_silu_nhwc_bwd", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_abi_version", "ms_status_string")
+           "ms_dwconv3x3_silu_nhwc_bwd", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
+           "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_abi_version", "ms_status_string")
+ABI_VERSION = 3
 
 _lib = None
 
@@ -92,12 +94,16 @@ def lib():
     h.ms_ln_gate_fwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_i64, c_int, c_vp]
     h.ms_ln_gate_bwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
                                  c_i64, c_int, c_vp]
+    h.ms_layernorm_fwd.argtypes = [c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_i64, c_int, c_vp]
+    h.ms_layernorm_bwd.argtypes = [c_vp, c_i64, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]
+    h.ms_block_tail_fwd.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp]
+    h.ms_block_tail_bwd.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_i64, c_int, c_vp]
     h.ms_status_string.restype = ctypes.c_char_p
     h.ms_status_string.argtypes = [ctypes.c_int]
     for name in EXPORTS[:-1]:
         getattr(h, name).restype = ctypes.c_int
-    if h.ms_abi_version() != 2:
-        raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != 2 (stale build?)")
+    if h.ms_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != {ABI_VERSION} (stale build?)")
     _lib = h
     return h
 

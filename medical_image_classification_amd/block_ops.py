@@ -1,0 +1,133 @@
+"""torch.autograd wrappers of the HIP kernels around SS2D inside the two-branch block `SS_Conv_SSM`
+(MedMamba.py:502-538; C ABI: include/medscan.h):
+
+  layernorm_rows   <- `self.ln_1(right)` on the strided right half of the block input (MedMamba.py:512-515): reads
+                      the half in place, writes the dtype the in-projection consumes
+  split_halves     <- `input.chunk(2, dim=-1)`: same forward views, but ONE concat in backward instead of two
+                      zero-fill + slice-copy + add chains
+  block_tail       <- drop_path + `torch.cat((left, x), -1)` + `channel_shuffle(.., 2)` + `+ input`
+                      (MedMamba.py:515,534-538,486-499) in one pass; the residual's gradient is `dout` itself
+All need CUDA (HIP) tensors and raise RuntimeError otherwise -- no CPU fallback.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+class _LayerNormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_bf16):
+        _lib.require_cuda(x, weight, bias)
+        D = x.shape[-1]
+        if x.dtype != torch.float32:
+            x = x.float()
+        ps = x.stride(-2) if x.dim() > 1 else D
+        # rows must be addressable as pixel * ps: unit channel stride and a uniform pixel stride over all leading dims
+        ok = x.stride(-1) == 1 and ps >= D
+        if ok:
+            exp = ps
+            for d in range(x.dim() - 2, -1, -1):
+                if x.shape[d] != 1 and x.stride(d) != exp:
+                    ok = False
+                    break
+                exp *= x.shape[d]
+        if not ok:
+            x = x.contiguous(); ps = D
+        npix = x.numel() // D
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_layernorm_fwd(x.data_ptr(), ps, w.data_ptr(), b.data_ptr(), float(eps), out.data_ptr(),
+                                                   int(out_bf16), npix, D, _stream(x)), "ms_layernorm_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.ps, ctx.eps, ctx.wdtype, ctx.bdtype = ps, float(eps), weight.dtype, bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        D = x.shape[-1]
+        npix = x.numel() // D
+        if dout.dtype not in (torch.float32, torch.bfloat16):
+            dout = dout.float()
+        dout = dout.contiguous()
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        dgb = torch.zeros((2, D), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_layernorm_bwd(x.data_ptr(), ctx.ps, w.data_ptr(), ctx.eps, dout.data_ptr(),
+                                                   int(dout.dtype == torch.bfloat16), dx.data_ptr(), dgb[0].data_ptr(),
+                                                   dgb[1].data_ptr(), npix, D, _stream(x)), "ms_layernorm_bwd")
+        return dx, dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None
+
+
+def layernorm_rows(x, weight, bias, eps, out_bf16=None):
+    """LayerNorm over the last axis of a (.., D) fp32 tensor that may be a channel slice of a wider tensor.
+    out_bf16=None: bf16 when CUDA autocast to bf16 is on (what the next linear would cast to), fp32 otherwise."""
+    if out_bf16 is None:
+        out_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    return _LayerNormRows.apply(x, weight, bias, eps, bool(out_bf16))
+
+
+class _SplitHalves(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        half = x.shape[-1] // 2
+        return x[..., :half], x[..., half:]
+
+    @staticmethod
+    def backward(ctx, dl, dr):
+        return torch.cat((dl.float(), dr.float()), dim=-1)
+
+
+def split_halves(x):
+    """`x.chunk(2, dim=-1)` (views) whose backward is a single concat."""
+    return _SplitHalves.apply(x)
+
+
+class _BlockTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, x, inp, scale):
+        _lib.require_cuda(left, x, inp)
+        B, H, W, C = inp.shape
+        half = C // 2
+        if tuple(left.shape) != (B, H, W, half) or tuple(x.shape) != (B, H, W, half):
+            raise RuntimeError(f"block_tail: halves must be {(B, H, W, half)}, got {tuple(left.shape)} and {tuple(x.shape)}")
+        if C % 4 != 0:
+            raise RuntimeError("block_tail: channel count must be a multiple of 4")
+        norm = lambda t: (t if t.dtype in (torch.float32, torch.bfloat16) else t.float()).contiguous()
+        left, x = norm(left), norm(x)
+        inp = inp.float().contiguous()
+        sc = scale.detach().float().contiguous().view(-1) if scale is not None else None
+        if sc is not None and sc.numel() != B:
+            raise RuntimeError("block_tail: sample_scale must have one entry per sample")
+        out = torch.empty_like(inp)
+        with torch.cuda.device(inp.device):
+            _lib.check(_lib.lib().ms_block_tail_fwd(left.data_ptr(), int(left.dtype == torch.bfloat16), x.data_ptr(),
+                                                    int(x.dtype == torch.bfloat16), inp.data_ptr(),
+                                                    sc.data_ptr() if sc is not None else None, out.data_ptr(),
+                                                    B * H * W, H * W, C, _stream(inp)), "ms_block_tail_fwd")
+        ctx.scale, ctx.ldt, ctx.xdt = sc, left.dtype, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.float().contiguous()
+        B, H, W, C = dout.shape
+        dl = torch.empty((B, H, W, C // 2), device=dout.device, dtype=ctx.ldt)
+        dx = torch.empty((B, H, W, C // 2), device=dout.device, dtype=ctx.xdt)
+        sc = ctx.scale
+        with torch.cuda.device(dout.device):
+            _lib.check(_lib.lib().ms_block_tail_bwd(dout.data_ptr(), sc.data_ptr() if sc is not None else None, dl.data_ptr(),
+                                                    int(ctx.ldt == torch.bfloat16), dx.data_ptr(), int(ctx.xdt == torch.bfloat16),
+                                                    B * H * W, H * W, C, _stream(dout)), "ms_block_tail_bwd")
+        return dl, dx, dout, None
+
+
+def block_tail(left, x, inp, sample_scale=None):
+    """channel_shuffle(cat(left, sample_scale * x), groups=2) + inp for channel-last (B,H,W,C/2) halves and a (B,H,W,C) input."""
+    return _BlockTail.apply(left, x, inp, sample_scale)

@@ -22,6 +22,14 @@ int ln_gate_fwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16,
 int ln_gate_bwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
                          const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz,
                          float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
+int block_tail_fwd_dispatch(const void *left, int left_is_bf16, const void *x, int x_is_bf16, const float *input,
+                            const float *scale, float *out, int64_t npix, int64_t hw, int C, hipStream_t s);
+int block_tail_bwd_dispatch(const float *dout, const float *scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
+                            int64_t npix, int64_t hw, int C, hipStream_t s);
+int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
+                    int out_bf16, int64_t npix, int D, hipStream_t s);
+int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
+                    float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
 }  // namespace ms
 
 extern "C" {
@@ -80,6 +88,28 @@ int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_
                    float *dy, void *dz, float *dgamma, float *dbeta, int64_t npix, int D, void *stream) {
     return ms::ln_gate_bwd_dispatch(y4, dir_stride, z, z_is_bf16, z_pixel_stride, gamma, beta, eps, dout, dout_is_bf16,
                                     dy, dz, dgamma, dbeta, npix, D, (hipStream_t)stream);
+}
+
+int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_is_bf16, const float *input,
+                      const float *sample_scale, float *out, int64_t npix, int64_t pixels_per_sample, int C, void *stream) {
+    return ms::block_tail_fwd_dispatch(left, left_is_bf16, x, x_is_bf16, input, sample_scale, out, npix, pixels_per_sample, C,
+                                       (hipStream_t)stream);
+}
+
+int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
+                      int64_t npix, int64_t pixels_per_sample, int C, void *stream) {
+    return ms::block_tail_bwd_dispatch(dout, sample_scale, dleft, dleft_is_bf16, dx, dx_is_bf16, npix, pixels_per_sample, C,
+                                       (hipStream_t)stream);
+}
+
+int ms_layernorm_fwd(const float *x, int64_t x_pixel_stride, const float *gamma, const float *beta, float eps, void *out,
+                     int out_is_bf16, int64_t npix, int D, void *stream) {
+    return ms::ln_fwd_dispatch(x, x_pixel_stride, gamma, beta, eps, out, out_is_bf16, npix, D, (hipStream_t)stream);
+}
+
+int ms_layernorm_bwd(const float *x, int64_t x_pixel_stride, const float *gamma, float eps, const void *dout, int dout_is_bf16,
+                     float *dx, float *dgamma, float *dbeta, int64_t npix, int D, void *stream) {
+    return ms::ln_bwd_dispatch(x, x_pixel_stride, gamma, eps, dout, dout_is_bf16, dx, dgamma, dbeta, npix, D, (hipStream_t)stream);
 }
 
 int ms_abi_version(void) { return MEDSCAN_ABI_VERSION; }

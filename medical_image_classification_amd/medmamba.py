@@ -21,6 +21,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
+from .block_ops import block_tail, layernorm_rows, split_halves
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_splitk
@@ -31,6 +32,8 @@ FUSED = os.environ.get("MEDSCAN_FUSED", "1") != "0"
 # The dense-conv branch of SS_Conv_SSM consumes and produces NHWC tokens; with channels_last the two permute copies
 # around it (MedMamba.py:533,535) become views and MIOpen runs its NHWC kernels.
 CONV_CHANNELS_LAST = os.environ.get("MEDSCAN_CONV_CL", "1") == "1"
+# SS_Conv_SSM: in-place LayerNorm of the right half + one-pass cat/shuffle/drop-path/residual tail (block_ops.py)
+BLOCK_FUSED = os.environ.get("MEDSCAN_BLOCK_FUSED", "1") == "1"
 
 
 class DropPath(nn.Module):
@@ -49,6 +52,16 @@ class DropPath(nn.Module):
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
         return x * mask
+
+    def sample_scale(self, x):
+        """The per-sample factor of forward() as a (B,) fp32 tensor (None when inactive): same draws, same scaling."""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return mask
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob}"
@@ -268,6 +281,13 @@ class SS_Conv_SSM(nn.Module):
         )
 
     def forward(self, input: torch.Tensor):
+        if BLOCK_FUSED and input.is_cuda and input.shape[-1] % 4 == 0 and type(self.ln_1) is nn.LayerNorm \
+                and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
+            # same arithmetic, fused around the SS2D path: in-place LayerNorm of the right half, one-pass tail
+            left, right = split_halves(input)
+            x = self.self_attention(layernorm_rows(right, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps))
+            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+            return block_tail(left.permute(0, 2, 3, 1), x, input, self.drop_path.sample_scale(x))
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))
         if CONV_CHANNELS_LAST and left.is_cuda:

@@ -288,3 +288,91 @@ def test_medmamba_b_512_train_step_runs():
     for n, p in net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all().item(), n
     assert not torch.equal(before, net.head.weight.detach())
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 96), (1, 7, 7, 768), (3, 2, 5, 70), (1, 1, 1, 130), (2, 56, 56, 48)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_layernorm_rows_strided_vs_torch(cfg, bf16):
+    """ms_layernorm_fwd/bwd on the right half of a (B,H,W,2D) tensor read in place, against F.layer_norm in float64."""
+    from medical_image_classification_amd.block_ops import layernorm_rows
+    B, H, W, D = cfg
+    gen = torch.Generator().manual_seed(3)
+    full = torch.randn(B, H, W, 2 * D, generator=gen) * 2 + 0.5
+    w, b = torch.randn(D, generator=gen), torch.randn(D, generator=gen)
+    g = torch.randn(B, H, W, D, generator=gen)
+    fr = full.double().requires_grad_(); wr = w.double().requires_grad_(); br = b.double().requires_grad_()
+    yr = F.layer_norm(fr[..., D:], (D,), wr, br, 1e-6)
+    yr.backward(g.double())
+    fd = full.to(dev()).requires_grad_(); wd = w.to(dev()).requires_grad_(); bd = b.to(dev()).requires_grad_()
+    yd = layernorm_rows(fd[..., D:], wd, bd, 1e-6, out_bf16=bf16)
+    assert yd.dtype == (torch.bfloat16 if bf16 else torch.float32) and yd.is_contiguous()
+    yd.backward(g.to(dev()).to(yd.dtype))
+    tol = 2e-2 if bf16 else 1e-4
+    assert_close(yd, yr.detach().float().numpy(), tol, tol * float(yr.abs().max()), "y")
+    gr = fr.grad.float().numpy()
+    assert np.array_equal(fd.grad[..., :D].cpu().numpy(), np.zeros_like(gr[..., :D]))
+    assert_close(fd.grad, gr, tol, tol * float(np.abs(gr).max()), "dx")
+    assert_close(wd.grad, wr.grad.float().numpy(), tol, tol * float(wr.grad.abs().max()), "dw")
+    assert_close(bd.grad, br.grad.float().numpy(), tol, tol * float(br.grad.abs().max()), "db")
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 96), (1, 7, 7, 768), (3, 2, 5, 12), (2, 56, 56, 96)])
+@pytest.mark.parametrize("dt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                (torch.bfloat16, torch.float32), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_block_tail_bit_exact_vs_torch(cfg, dt, scaled):
+    """ms_block_tail_fwd/bwd == channel_shuffle(cat(left, s*x), 2) + input and its autograd (pure data movement plus
+    one fma per element: bit-exact in fp32, one bf16 rounding for bf16 gradients)."""
+    from medical_image_classification_amd.block_ops import block_tail
+    from medical_image_classification_amd.medmamba import channel_shuffle
+    B, H, W, C = cfg
+    gen = torch.Generator().manual_seed(5)
+    left = torch.randn(B, H, W, C // 2, generator=gen).to(dt[0])
+    x = torch.randn(B, H, W, C // 2, generator=gen).to(dt[1])
+    inp = torch.randn(B, H, W, C, generator=gen)
+    g = torch.randn(B, H, W, C, generator=gen)
+    scale = (torch.rand(B, generator=gen) > 0.3).float() / 0.7 if scaled else None
+    lr, xr, ir = (t.clone().requires_grad_() for t in (left, x, inp))
+    xs = xr.float() * scale.view(B, 1, 1, 1) if scaled else xr.float()
+    yr = channel_shuffle(torch.cat((lr.float(), xs), dim=-1), 2) + ir
+    yr.backward(g)
+    ld_, xd, id_ = (t.to(dev()).requires_grad_() for t in (left, x, inp))
+    yd = block_tail(ld_, xd, id_, scale.to(dev()) if scaled else None)
+    yd.backward(g.to(dev()))
+    # forward: fma(s, x, in) vs (s*x) + in differ by one rounding when scaled
+    if scaled:
+        assert_close(yd, yr.detach().numpy(), 1e-6, 1e-6, "y")
+    else:
+        assert np.array_equal(yd.detach().cpu().numpy(), yr.detach().numpy())
+    assert np.array_equal(id_.grad.cpu().numpy(), ir.grad.numpy())
+    assert ld_.grad.dtype == dt[0] and xd.grad.dtype == dt[1]
+    assert np.array_equal(ld_.grad.float().cpu().numpy(), lr.grad.float().numpy())
+    assert np.array_equal(xd.grad.float().cpu().numpy(), xr.grad.float().numpy())
+
+
+def test_fused_block_matches_unfused_block(monkeypatch):
+    """SS_Conv_SSM with the fused LayerNorm / tail kernels == the op-by-op block (same parameters, same input), with
+    an active DropPath (same RNG stream on both sides)."""
+    from medical_image_classification_amd import medmamba as mm
+    torch.manual_seed(11)
+    blk = mm.SS_Conv_SSM(hidden_dim=96, drop_path=0.3).to(dev()).train()
+    x = torch.randn(4, 14, 14, 96, device=dev())
+    g = torch.randn(4, 14, 14, 96, device=dev())
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(mm, "BLOCK_FUSED", fused)
+        blk.zero_grad(set_to_none=True)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        xi = x.clone().requires_grad_()
+        torch.manual_seed(123); torch.cuda.manual_seed(123)
+        y = blk(xi)
+        y.backward(g)
+        outs.append((y.detach(), xi.grad.detach(), {k: p.grad.detach().clone() for k, p in blk.named_parameters()}))
+    (y1, dx1, p1), (y0, dx0, p0) = outs
+    assert_close(y1, y0.cpu().numpy(), 1e-4, 1e-4 * float(y0.abs().max()), "y")
+    assert_close(dx1, dx0.cpu().numpy(), 1e-3, 1e-4 * float(dx0.abs().max()), "dx")
+    for k in p0:
+        r = p0[k].cpu().numpy()
+        assert_close(p1[k], r, 1e-2, max(1e-5, 1e-3 * float(np.abs(r).max())), k)
