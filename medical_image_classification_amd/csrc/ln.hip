@@ -10,7 +10,6 @@
 namespace ms {
 
 constexpr int kLnMaxVPT = 16;          // D <= 1024
-constexpr int kLnPixPerWaveBwd = 8;
 
 __device__ __forceinline__ float ln_wave_sum(float v) {
 #pragma unroll
@@ -48,7 +47,23 @@ ln_fwd_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict_
     }
 }
 
-template <int VPT, typename TG>
+// sums of PB independent values at once: the PB shuffle chains overlap instead of running back to back
+template <int PB>
+__device__ __forceinline__ void ln_wave_sum_n(float (&v)[PB]) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        float t[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) t[q] = __shfl_xor(v[q], s, 64);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) v[q] += t[q];
+    }
+}
+
+// Backward: a wave works on PB pixels at a time (all loads of the PB pixels are
+// issued before the first reduction, the PB reduction chains are interleaved): the kernel is latency-bound otherwise
+// (one pixel = 5 dependent wave reductions behind a global load).
+template <int VPT, int PB, typename TG>
 __global__ void __launch_bounds__(256)
 ln_bwd_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict__ gamma, float eps,
               const TG *__restrict__ dout, float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
@@ -58,40 +73,63 @@ ln_bwd_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict_
     float gm[VPT], dg[VPT], db[VPT];
 #pragma unroll
     for (int j = 0; j < VPT; ++j) { const int c = lane + 64 * j; gm[j] = c < D ? gamma[c] : 0.0f; dg[j] = 0.0f; db[j] = 0.0f; }
-    const int64_t first = ((int64_t)blockIdx.x * 4 + wv) * kLnPixPerWaveBwd;
-    for (int64_t pix = first; pix < first + kLnPixPerWaveBwd && pix < npix; ++pix) {
-        const float *xp = x + pix * xps;
-        float v[VPT], g[VPT];
-        float s1 = 0.0f;
+    // persistent waves: wave w takes pixel groups w, w + nwaves, ... and keeps its dgamma/dbeta partial sums in registers
+    // over all of them, so the same-address atomics at the end number gridDim.x per channel (they, not the
+    // arithmetic, bounded the one-group-per-wave version: 6272 serialized atomics per address at stage 0)
+    const int64_t nwaves = (int64_t)gridDim.x * 4, last = npix;
+    const float invD = 1.0f / (float)D;
+    for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB; p0 < last; p0 += nwaves * PB) {
+        float v[PB][VPT], g[PB][VPT], s1[PB];
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int c = lane + 64 * j;
-            v[j] = c < D ? xp[c] : 0.0f;
-            g[j] = c < D ? ln_ld(dout + pix * D + c) : 0.0f;
-            s1 += v[j];
+        for (int q = 0; q < PB; ++q) {
+            const int64_t pix = min(p0 + q, last - 1);           // duplicates of the last pixel are computed, not stored
+            s1[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const int c = lane + 64 * j;
+                v[q][j] = c < D ? x[pix * xps + c] : 0.0f;
+                g[q][j] = c < D ? ln_ld(dout + pix * D + c) : 0.0f;
+                s1[q] += v[q][j];
+            }
         }
-        const float mean = ln_wave_sum(s1) / (float)D;
-        float s2 = 0.0f;
+        ln_wave_sum_n<PB>(s1);
+        float s2[PB];
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) { const float d = (lane + 64 * j < D) ? v[j] - mean : 0.0f; s2 += d * d; }
-        const float rstd = rsqrtf(ln_wave_sum(s2) / (float)D + eps);
-        float m1 = 0.0f, m2 = 0.0f;
+        for (int q = 0; q < PB; ++q) {
+            s1[q] *= invD; s2[q] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const bool in = lane + 64 * j < D;
-            v[j] = in ? (v[j] - mean) * rstd : 0.0f;          // normalised value
-            dg[j] = fmaf(g[j], v[j], dg[j]);
-            db[j] += g[j];
-            g[j] *= gm[j];                                     // gradient w.r.t. the normalised value
-            m1 += g[j];
-            m2 = fmaf(g[j], v[j], m2);
+            for (int j = 0; j < VPT; ++j) { const float d = (lane + 64 * j < D) ? v[q][j] - s1[q] : 0.0f; s2[q] += d * d; }
         }
-        m1 = ln_wave_sum(m1) / (float)D;
-        m2 = ln_wave_sum(m2) / (float)D;
+        ln_wave_sum_n<PB>(s2);
+        float m[2 * PB];
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) dx[pix * D + c] = rstd * (g[j] - m1 - v[j] * m2);
+        for (int q = 0; q < PB; ++q) {
+            const float rstd = rsqrtf(s2[q] * invD + eps);
+            const bool live = p0 + q < last;
+            s2[q] = rstd;
+            float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const bool in = lane + 64 * j < D;
+                v[q][j] = in ? (v[q][j] - s1[q]) * rstd : 0.0f;          // normalised value
+                if (live) { dg[j] = fmaf(g[q][j], v[q][j], dg[j]); db[j] += g[q][j]; }
+                g[q][j] *= gm[j];                                         // gradient w.r.t. the normalised value
+                m1 += g[q][j];
+                m2 = fmaf(g[q][j], v[q][j], m2);
+            }
+            m[2 * q] = m1; m[2 * q + 1] = m2;
+        }
+        ln_wave_sum_n<2 * PB>(m);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            if (p0 + q < last) {
+                const float m1 = m[2 * q] * invD, m2 = m[2 * q + 1] * invD;
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < D) dx[(p0 + q) * D + c] = s2[q] * (g[q][j] - m1 - v[q][j] * m2);
+                }
+            }
         }
     }
     if (wv > 0) {
@@ -140,18 +178,26 @@ int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, 
     if (!x || !gamma || !dout || !dx || !dgamma || !dbeta) return MS_ERR_NULL;
     if (D <= 0 || D > 64 * kLnMaxVPT || npix < 0 || xps < D) return MS_ERR_SHAPE;
     if (npix == 0) return MS_OK;
-    const int64_t tasks = (npix + kLnPixPerWaveBwd - 1) / kLnPixPerWaveBwd;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
     const int vpt = (D + 63) / 64;
+    const int pb = vpt <= 2 ? 4 : vpt <= 4 ? 2 : 1;                 // = MS_PB of the dispatched VPT bucket
+    const int64_t tasks = (npix + pb - 1) / pb;                     // pixel groups
+    const int64_t blocks = (tasks + 3) / 4;
+    // measured optimum (tools/bench_ln.py): enough waves to keep HBM busy, few enough that the closing burst of
+    // same-address dgamma/dbeta atomics stays short
+    const int64_t cap = npix >= 131072 ? 1024 : npix >= 32768 ? 512 : 256;
+    const dim3 grid((unsigned)(blocks < cap ? blocks : cap)), block(256);
+    // PB pixels in flight per wave: 4 for narrow rows, fewer as the row itself supplies the parallelism
+#define MS_PB(V) ((V) <= 2 ? 4 : (V) <= 4 ? 2 : 1)
     if (dout_bf16) {
-#define MS_C(V) hipLaunchKernelGGL((ln_bwd_kernel<V, unsigned short>), grid, block, 0, s, x, xps, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix)
+#define MS_C(V) hipLaunchKernelGGL((ln_bwd_kernel<V, MS_PB(V), unsigned short>), grid, block, 0, s, x, xps, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix)
         MS_LN_DISPATCH(vpt, MS_C)
 #undef MS_C
     } else {
-#define MS_C(V) hipLaunchKernelGGL((ln_bwd_kernel<V, float>), grid, block, 0, s, x, xps, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix)
+#define MS_C(V) hipLaunchKernelGGL((ln_bwd_kernel<V, MS_PB(V), float>), grid, block, 0, s, x, xps, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix)
         MS_LN_DISPATCH(vpt, MS_C)
 #undef MS_C
     }
+#undef MS_PB
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

@@ -61,9 +61,21 @@ ln_gate_fwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
     }
 }
 
-constexpr int kPixPerWaveBwd = 8;
+template <int PB>
+__device__ __forceinline__ void wave_sum_n(float (&v)[PB]) {         // PB interleaved shuffle chains
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        float t[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) t[q] = __shfl_xor(v[q], s, 64);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) v[q] += t[q];
+    }
+}
 
-template <int VPT, typename TZ, typename TG>
+// Backward: a wave works on PB pixels at a time (loads of all PB pixels first, the
+// reduction chains interleaved): one pixel alone is 5 dependent wave reductions behind its global loads.
+template <int VPT, int PB, typename TZ, typename TG>
 __global__ void __launch_bounds__(256)
 ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restrict__ z, int64_t zps,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -77,49 +89,71 @@ ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
         const int c = lane + 64 * j;
         gm[j] = c < D ? gamma[c] : 0.0f; bt[j] = c < D ? beta[c] : 0.0f; dg[j] = 0.0f; db[j] = 0.0f;
     }
-    const int64_t first = ((int64_t)blockIdx.x * 4 + wv) * kPixPerWaveBwd;
-    for (int64_t pix = first; pix < first + kPixPerWaveBwd && pix < npix; ++pix) {
-        const float *yp = y4 + pix * D;
-        float y[VPT];
-        float s1 = 0.0f;
+    // persistent waves: wave w takes pixel groups w, w + nwaves, ... and keeps its dgamma/dbeta partial sums in registers
+    // over all of them, so the same-address atomics at the end number gridDim.x per channel (they, not the
+    // arithmetic, bounded the one-group-per-wave version: 6272 serialized atomics per address at stage 0)
+    const int64_t nwaves = (int64_t)gridDim.x * 4, last = npix;
+    const float invD = 1.0f / (float)D;
+    for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB; p0 < last; p0 += nwaves * PB) {
+        float y[PB][VPT], zz[PB][VPT], g[PB][VPT], s1[PB];
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int c = lane + 64 * j;
-            y[j] = c < D ? ((yp[c] + yp[2 * sk + c]) + yp[sk + c]) + yp[3 * sk + c] : 0.0f;
-            s1 += y[j];
-        }
-        const float mean = wave_sum(s1) / (float)D;
-        float s2 = 0.0f;
+        for (int q = 0; q < PB; ++q) {
+            const int64_t pix = min(p0 + q, last - 1);           // duplicates of the last pixel are computed, not stored
+            const float *yp = y4 + pix * D;
+            s1[q] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) { const float d = (lane + 64 * j < D) ? y[j] - mean : 0.0f; s2 += d * d; }
-        const float rstd = rsqrtf(wave_sum(s2) / (float)D + eps);
-        float dyn[VPT], yn[VPT];
-        float m1 = 0.0f, m2 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int c = lane + 64 * j;
-            dyn[j] = 0.0f; yn[j] = 0.0f;
-            if (c < D) {
-                const float zz = ld(z + pix * zps + c);
-                const float g = ld(dout + pix * D + c);
-                const float sg = 1.0f / (1.0f + expf(-zz));
-                yn[j] = (y[j] - mean) * rstd;
-                const float yh = yn[j] * gm[j] + bt[j];
-                st(dz + pix * D + c, g * yh * (sg * (1.0f + zz * (1.0f - sg))));
-                const float dyh = g * (zz * sg);
-                dg[j] = fmaf(dyh, yn[j], dg[j]);
-                db[j] += dyh;
-                dyn[j] = dyh * gm[j];
-                m1 += dyn[j];
-                m2 = fmaf(dyn[j], yn[j], m2);
+            for (int j = 0; j < VPT; ++j) {
+                const int c = lane + 64 * j;
+                y[q][j] = c < D ? ((yp[c] + yp[2 * sk + c]) + yp[sk + c]) + yp[3 * sk + c] : 0.0f;
+                zz[q][j] = c < D ? ld(z + pix * zps + c) : 0.0f;
+                g[q][j] = c < D ? ld(dout + pix * D + c) : 0.0f;
+                s1[q] += y[q][j];
             }
         }
-        m1 = wave_sum(m1) / (float)D;
-        m2 = wave_sum(m2) / (float)D;
+        wave_sum_n<PB>(s1);
+        float s2[PB];
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) dy[pix * D + c] = rstd * (dyn[j] - m1 - yn[j] * m2);
+        for (int q = 0; q < PB; ++q) {
+            s1[q] *= invD; s2[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) { const float d = (lane + 64 * j < D) ? y[q][j] - s1[q] : 0.0f; s2[q] += d * d; }
+        }
+        wave_sum_n<PB>(s2);
+        float m[2 * PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const float rstd = rsqrtf(s2[q] * invD + eps);
+            const bool live = p0 + q < last;
+            s2[q] = rstd;
+            float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const int c = lane + 64 * j;
+                const bool in = c < D;
+                const float sg = 1.0f / (1.0f + expf(-zz[q][j]));
+                const float yn = in ? (y[q][j] - s1[q]) * rstd : 0.0f;
+                const float yh = yn * gm[j] + bt[j];
+                if (in && live) st(dz + (p0 + q) * D + c, g[q][j] * yh * (sg * (1.0f + zz[q][j] * (1.0f - sg))));
+                const float dyh = in ? g[q][j] * (zz[q][j] * sg) : 0.0f;
+                if (live) { dg[j] = fmaf(dyh, yn, dg[j]); db[j] += dyh; }
+                y[q][j] = yn;                                    // y <- normalised value
+                g[q][j] = dyh * gm[j];                           // g <- gradient w.r.t. the normalised value
+                m1 += g[q][j];
+                m2 = fmaf(g[q][j], yn, m2);
+            }
+            m[2 * q] = m1; m[2 * q + 1] = m2;
+        }
+        wave_sum_n<2 * PB>(m);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            if (p0 + q < last) {
+                const float m1 = m[2 * q] * invD, m2 = m[2 * q + 1] * invD;
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < D) dy[(p0 + q) * D + c] = s2[q] * (g[q][j] - m1 - y[q][j] * m2);
+                }
+            }
         }
     }
     // gamma / beta gradients: combine the block's 4 waves in LDS, then one atomic per (block, channel)
@@ -167,13 +201,18 @@ template <typename TZ, typename TG>
 static int launch_bwd(const float *y4, int64_t sk, const void *z, int64_t zps, const float *gamma, const float *beta,
                       float eps, const void *dout, float *dy, void *dz, float *dgamma, float *dbeta, int D,
                       int64_t npix, hipStream_t s) {
-    const int64_t tasks = (npix + kPixPerWaveBwd - 1) / kPixPerWaveBwd;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
     const int vpt = (D + 63) / 64;
-#define MS_L(V) hipLaunchKernelGGL((ln_gate_bwd_kernel<V, TZ, TG>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix)
+    const int pb = vpt <= 2 ? 4 : vpt <= 4 ? 2 : 1;                 // = MS_PB of the dispatched VPT bucket
+    const int64_t tasks = (npix + pb - 1) / pb;                     // pixel groups
+    const int64_t blocks = (tasks + 3) / 4;
+    const int64_t cap = npix >= 32768 ? 1024 : 512;      // measured optimum (tools/bench_ln.py), see ln.hip
+    const dim3 grid((unsigned)(blocks < cap ? blocks : cap)), block(256);      // persistent
+#define MS_PB(V) ((V) <= 2 ? 4 : (V) <= 4 ? 2 : 1)
+#define MS_L(V) hipLaunchKernelGGL((ln_gate_bwd_kernel<V, MS_PB(V), TZ, TG>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix)
     if (vpt <= 1) MS_L(1); else if (vpt <= 2) MS_L(2); else if (vpt <= 3) MS_L(3); else if (vpt <= 4) MS_L(4);
     else if (vpt <= 6) MS_L(6); else if (vpt <= 8) MS_L(8); else if (vpt <= 12) MS_L(12); else MS_L(16);
 #undef MS_L
+#undef MS_PB
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
