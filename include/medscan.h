@@ -172,6 +172,17 @@ int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_i
 int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
                       int64_t npix, int64_t pixels_per_sample, int C, void *stream);
 
+/* ---- delta projection of SS2D (the `dt_projs` einsum, MedMamba.py:400,403-405) -------------------------------------
+ * proj   (npix, 4, row_width) fp32: the x_proj output rows [dts(R) | B(N) | C(N)] of every (pixel, direction)
+ * Wdt    (4, D, R) fp32 = dt_projs_weight;  delta / ddelta (4, npix, D) fp32;  R <= 32
+ * fwd:   delta[k, m, d] = sum_r proj[m, k, r] * Wdt[k, d, r]            (bias and softplus stay inside the scan kernel)
+ * bwd:   dproj[m, k, r] (r < R) (+)= sum_d ddelta[k, m, d] * Wdt[k, d, r]   -- written in place into the projection gradient
+ *        whose B|C columns ms_selective_scan_bwd fills; dproj must be zero-initialised (shared with that kernel's rule)
+ *        dWdt[k, d, r] += sum_m ddelta[k, m, d] * proj[m, k, r]             -- accumulated (zero it first) */
+int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npix, int D, int R, int row_width, void *stream);
+int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
+                  int row_width, void *stream);
+
 int ms_abi_version(void);
 const char *ms_status_string(int status);
 

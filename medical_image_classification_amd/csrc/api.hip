@@ -30,6 +30,9 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
                     int out_bf16, int64_t npix, int D, hipStream_t s);
 int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
                     float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
+int dtproj_fwd_dispatch(const float *proj, const float *W, float *delta, int64_t npix, int D, int R, int C, hipStream_t s);
+int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, int64_t npix, int D,
+                        int R, int C, hipStream_t s);
 }  // namespace ms
 
 extern "C" {
@@ -110,6 +113,15 @@ int ms_layernorm_fwd(const float *x, int64_t x_pixel_stride, const float *gamma,
 int ms_layernorm_bwd(const float *x, int64_t x_pixel_stride, const float *gamma, float eps, const void *dout, int dout_is_bf16,
                      float *dx, float *dgamma, float *dbeta, int64_t npix, int D, void *stream) {
     return ms::ln_bwd_dispatch(x, x_pixel_stride, gamma, eps, dout, dout_is_bf16, dx, dgamma, dbeta, npix, D, (hipStream_t)stream);
+}
+
+int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npix, int D, int R, int row_width, void *stream) {
+    return ms::dtproj_fwd_dispatch(proj, Wdt, delta, npix, D, R, row_width, (hipStream_t)stream);
+}
+
+int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
+                  int row_width, void *stream) {
+    return ms::dtproj_bwd_dispatch(ddelta, proj, Wdt, dproj, dWdt, npix, D, R, row_width, (hipStream_t)stream);
 }
 
 int ms_abi_version(void) { return MEDSCAN_ABI_VERSION; }

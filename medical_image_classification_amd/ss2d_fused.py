@@ -84,16 +84,40 @@ def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R):
     P.x = x_state.data_ptr()
 
 
+def _dtproj_fwd(proj, wdt, B, L, D, R, C):
+    """delta (4,B,L,D) = dts @ Wdt^T with dts read in place from the projection rows (ms_dtproj_fwd)."""
+    delta = torch.empty((4, B, L, D), device=proj.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ms_dtproj_fwd(proj.data_ptr(), wdt.data_ptr(), delta.data_ptr(), B * L, D, R, C,
+                                        _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd")
+    return delta
+
+
+def _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C):
+    """ddts into the first R columns of dproj (in place), returns dWdt (4,D,R)."""
+    dwdt = torch.zeros_like(wdt)
+    _lib.check(_lib.lib().ms_dtproj_bwd(ddelta.data_ptr(), proj.data_ptr(), wdt.data_ptr(), dproj.data_ptr(), dwdt.data_ptr(),
+                                        B * L, D, R, C, _lib.current_stream_ptr(proj.device)), "ms_dtproj_bwd")
+    return dwdt
+
+
 class _SS2DScan(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xc, proj, delta, A, Ds, dt_bias, H, W, N, R):
-        """xc (B,H,W,D), proj (B,L,4,R+2N), delta (4,B,L,D), A (4D,N), Ds (4D), dt_bias (4D): fp32 contiguous.
+    def forward(ctx, xc, proj, delta, wdt, A, Ds, dt_bias, H, W, N, R):
+        """xc (B,H,W,D), proj (B,L,4,R+2N), A (4D,N), Ds (4D), dt_bias (4D): fp32 contiguous; either delta (4,B,L,D) or
+        wdt (4,D,R) (then delta = dts @ wdt^T is computed here, ms_dtproj_fwd).
         Returns y (B,L,D) = ((y0 + y2) + y1) + y3 with every y_k in pixel order (add order of MedMamba.py:476)."""
-        _lib.require_cuda(xc, proj, delta, A, Ds, dt_bias)
+        _lib.require_cuda(xc, proj, A, Ds, dt_bias)
         lib = _lib.lib()
         B, D, L = xc.shape[0], xc.shape[-1], H * W
-        xc, proj, delta = xc.contiguous(), proj.contiguous(), delta.contiguous()
+        xc, proj = xc.contiguous(), proj.contiguous()
         A, Ds, dt_bias = A.contiguous(), Ds.contiguous(), dt_bias.contiguous()
+        ctx.has_wdt = wdt is not None
+        with torch.cuda.device(xc.device):
+            if ctx.has_wdt:
+                wdt = wdt.detach().float().contiguous()
+                delta = _dtproj_fwd(proj, wdt, B, L, D, R, R + 2 * N)
+            else:
+                delta = delta.contiguous()
         y4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
         x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=xc.device, dtype=torch.float32)
         P = MsScanParams()
@@ -102,13 +126,13 @@ class _SS2DScan(torch.autograd.Function):
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
                               lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(xc.device)))
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
-        ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state)
+        ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state, wdt if ctx.has_wdt else None)
         ctx.geom = (H, W, N, R)
         return (y4[0] + y4[2]) + y4[1] + y4[3]
 
     @staticmethod
     def backward(ctx, dy):
-        xc, proj, delta, A, Ds, dt_bias, x_state = ctx.saved_tensors
+        xc, proj, delta, A, Ds, dt_bias, x_state, wdt = ctx.saved_tensors
         H, W, N, R = ctx.geom
         lib = _lib.lib()
         B, D, L = xc.shape[0], xc.shape[-1], H * W
@@ -132,8 +156,9 @@ class _SS2DScan(torch.autograd.Function):
             rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), xc.device,
                               lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(xc.device)))
             _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
+            dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C) if ctx.has_wdt else None
         dxc = du4.sum(dim=0).view_as(xc)
-        return dxc, dproj, ddelta, dA, dD, dbias, None, None, None, None
+        return dxc, dproj, (None if ctx.has_wdt else ddelta), dwdt, dA, dD, dbias, None, None, None, None
 
 
 def _pixel_view(t, D):
@@ -152,12 +177,19 @@ class _SS2DScanNormGate(torch.autograd.Function):
     outputs never pass through autograd, and the LayerNorm backward hands one (B,L,D) gradient to all four directions."""
 
     @staticmethod
-    def forward(ctx, xc, proj, delta, A, Ds, dt_bias, z, gamma, beta, eps, H, W, N, R, out_bf16):
-        _lib.require_cuda(xc, proj, delta, A, Ds, dt_bias, z, gamma, beta)
+    def forward(ctx, xc, proj, delta, wdt, A, Ds, dt_bias, z, gamma, beta, eps, H, W, N, R, out_bf16):
+        _lib.require_cuda(xc, proj, A, Ds, dt_bias, z, gamma, beta)
         lib = _lib.lib()
         B, D, L = xc.shape[0], xc.shape[-1], H * W
-        xc, proj, delta = xc.contiguous(), proj.contiguous(), delta.contiguous()
+        xc, proj = xc.contiguous(), proj.contiguous()
         A, Ds, dt_bias = A.contiguous(), Ds.contiguous(), dt_bias.contiguous()
+        ctx.has_wdt = wdt is not None
+        with torch.cuda.device(xc.device):
+            if ctx.has_wdt:
+                wdt = wdt.detach().float().contiguous()
+                delta = _dtproj_fwd(proj, wdt, B, L, D, R, R + 2 * N)
+            else:
+                delta = delta.contiguous()
         gamma, beta = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         z, zps = _pixel_view(z, D)
         y4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
@@ -173,13 +205,13 @@ class _SS2DScanNormGate(torch.autograd.Function):
             _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, z.data_ptr(), int(z.dtype == torch.bfloat16), zps,
                                           gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16),
                                           B * L, D, stream), "ms_ln_gate_fwd")
-        ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state, y4, z, gamma, beta)
+        ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state, y4, z, gamma, beta, wdt if ctx.has_wdt else None)
         ctx.geom = (H, W, N, R, float(eps), zps)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xc, proj, delta, A, Ds, dt_bias, x_state, y4, z, gamma, beta = ctx.saved_tensors
+        xc, proj, delta, A, Ds, dt_bias, x_state, y4, z, gamma, beta, wdt = ctx.saved_tensors
         H, W, N, R, eps, zps = ctx.geom
         lib = _lib.lib()
         B, D, L = xc.shape[0], xc.shape[-1], H * W
@@ -213,34 +245,45 @@ class _SS2DScanNormGate(torch.autograd.Function):
             rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), xc.device,
                               lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream))
             _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
+            dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C) if ctx.has_wdt else None
         dxc = du4.sum(dim=0).view_as(xc)
-        return dxc, dproj, ddelta, dA, dD, dbias, dz, dgamma, dbeta, None, None, None, None, None, None
+        return (dxc, dproj, (None if ctx.has_wdt else ddelta), dwdt, dA, dD, dbias, dz, dgamma, dbeta,
+                None, None, None, None, None, None)
+
+
+# dt_rank up to which ms_dtproj_* replace the batched GEMMs.  Measured (tools/bench_dtproj.py, MedMamba-T bs 64, fwd+bwd us):
+# R=3: 284 vs 438 (kernels win: K is too small for a GEMM); R=6: 201 vs 142; R=12: 207 vs 113; R=24: 312 vs 75 (few
+# pixels, wide K: a real GEMM).  The kernels tile R <= 32; the product path uses them where they win.
+_DT_KERNEL_MAX_RANK = 4
 
 
 def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):
     """x_proj follows the ambient autocast (bf16 under autocast, like the reference's einsum would, MedMamba.py:397);
-    dt_proj (K = R <= 24) is fp32 always (MedMamba.py:403-409)."""
+    dt_proj (K = R <= 32) is fp32 always (MedMamba.py:403-409) and runs inside the scan's autograd node (ms_dtproj_*);
+    returns (proj (B,L,4,C), delta or None, Wdt or None)."""
     B, H, W, D = xc.shape
     N, R = d_state, dt_rank
     C = R + 2 * N
     M = B * H * W
     from .ss2d_ops import dt_proj_splitk, linear_splitk
     proj = linear_splitk(xc.view(M, D), x_proj_weight.view(4 * C, D)).float()               # (M, 4C)
+    if R <= _DT_KERNEL_MAX_RANK:
+        return proj.view(B, H * W, 4, C), None, dt_projs_weight
     with torch.autocast(device_type="cuda", enabled=False):
         dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                   # (4, M, R)
         delta = dt_proj_splitk(dts, dt_projs_weight.float())                                # (4, M, D)
-    return proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D)
+    return proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D), None
 
 
 def ss2d_core_norm_gate(xc, z, mod):
     """xc (B,H,W,D) fp32 conv output, z (B,H,W,D) gate (view of xz) -> out_norm(merge(scan)) * silu(z), (B,H,W,D) in the
     dtype out_proj will consume (bf16 under bf16 autocast, else fp32).  `mod` is the SS2D module (parameters)."""
     B, H, W, D = xc.shape
-    proj, delta = _projections(xc, mod.x_proj_weight, mod.dt_projs_weight, mod.d_state, mod.dt_rank)
+    proj, delta, wdt = _projections(xc, mod.x_proj_weight, mod.dt_projs_weight, mod.d_state, mod.dt_rank)
     out_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
     with torch.autocast(device_type="cuda", enabled=False):
         As = -torch.exp(mod.A_logs.float())
-        return _SS2DScanNormGate.apply(xc, proj, delta, As, mod.Ds.float().view(-1), mod.dt_projs_bias.float().view(-1),
+        return _SS2DScanNormGate.apply(xc, proj, delta, wdt, As, mod.Ds.float().view(-1), mod.dt_projs_bias.float().view(-1),
                                        z, mod.out_norm.weight, mod.out_norm.bias, mod.out_norm.eps, H, W,
                                        mod.d_state, mod.dt_rank, out_bf16)
 
@@ -248,9 +291,9 @@ def ss2d_core_norm_gate(xc, z, mod):
 def ss2d_core(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, d_state, dt_rank):
     """xc (B,H,W,D) fp32 -> merged scan output y (B,H,W,D) fp32 (without the norm/gate tail)."""
     B, H, W, D = xc.shape
-    proj, delta = _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank)
+    proj, delta, wdt = _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank)
     with torch.autocast(device_type="cuda", enabled=False):
         As = -torch.exp(A_logs.float())
-        y = _SS2DScan.apply(xc, proj, delta, As, Ds.float().view(-1), dt_projs_bias.float().view(-1), H, W,
+        y = _SS2DScan.apply(xc, proj, delta, wdt, As, Ds.float().view(-1), dt_projs_bias.float().view(-1), H, W,
                             d_state, dt_rank)
     return y.view(B, H, W, D)

@@ -376,3 +376,31 @@ def test_fused_block_matches_unfused_block(monkeypatch):
     for k in p0:
         r = p0[k].cpu().numpy()
         assert_close(p1[k], r, 1e-2, max(1e-5, 1e-3 * float(np.abs(r).max())), k)
+
+
+@pytest.mark.parametrize("cfg", [(200, 96, 3, 35), (64, 192, 6, 38), (50, 384, 12, 44), (49, 768, 24, 56), (33, 70, 5, 37),
+                                 (17, 1024, 32, 64), (9, 130, 1, 33), (64 * 56 * 56, 96, 3, 35)])
+def test_dtproj_kernels_vs_einsum(cfg):
+    """ms_dtproj_fwd/bwd (delta = dts @ Wdt^T read / written in place in the projection rows) vs float64 einsum."""
+    from medical_image_classification_amd import _lib
+    npix, D, R, C = cfg
+    h = _lib.lib()
+    gen = torch.Generator().manual_seed(9)
+    proj = torch.randn(npix, 4, C, generator=gen)
+    W = torch.randn(4, D, R, generator=gen)
+    dd = torch.randn(4, npix, D, generator=gen)
+    want = torch.einsum("mkr,kdr->kmd", proj[:, :, :R].double(), W.double())
+    ddts = torch.einsum("kmd,kdr->mkr", dd.double(), W.double())
+    dW = torch.einsum("kmd,mkr->kdr", dd.double(), proj[:, :, :R].double())
+    pj, Wd, ddd = proj.to(dev()), W.to(dev()), dd.to(dev())
+    delta = torch.empty(4, npix, D, device=dev())
+    st = _lib.current_stream_ptr(dev())
+    _lib.check(h.ms_dtproj_fwd(pj.data_ptr(), Wd.data_ptr(), delta.data_ptr(), npix, D, R, C, st), "fwd")
+    assert_close(delta, want.float().numpy(), 1e-5, 1e-5 * float(want.abs().max()), "delta")
+    dproj = torch.zeros(npix, 4, C, device=dev())
+    dproj[:, :, R:] = 7.0                                       # the B|C columns belong to the scan kernel: must stay untouched
+    dWd = torch.zeros(4, D, R, device=dev())
+    _lib.check(h.ms_dtproj_bwd(ddd.data_ptr(), pj.data_ptr(), Wd.data_ptr(), dproj.data_ptr(), dWd.data_ptr(), npix, D, R, C, st), "bwd")
+    assert torch.equal(dproj[:, :, R:], torch.full_like(dproj[:, :, R:], 7.0))
+    assert_close(dproj[:, :, :R], ddts.float().numpy(), 1e-4, 1e-5 * float(ddts.abs().max()), "ddts")
+    assert_close(dWd, dW.float().numpy(), 1e-4, 2e-5 * float(dW.abs().max()), "dW")

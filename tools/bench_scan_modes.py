@@ -39,5 +39,5 @@ for D, Hh, R in [(96, 56, 3), (192, 28, 6), (384, 14, 12), (768, 7, 24)]:
     proj = torch.randn(bs, L, 4, C, device=dev, generator=gen).requires_grad_()
     delta = (0.5 * torch.rand(4, bs, L, D, device=dev, generator=gen)).requires_grad_()
     gy = torch.randn(bs, L, D, device=dev, generator=gen)
-    t_ss = timeit(lambda: _SS2DScan.apply(xc, proj, delta, A, Dp, bias, Hh, Hh, N, R), gy)
+    t_ss = timeit(lambda: _SS2DScan.apply(xc, proj, delta, None, A, Dp, bias, Hh, Hh, N, R), gy)
     print(f"D={D:4d} L={L:5d}  fwd/bwd ms:  BDL {t_bdl[0]:.3f}/{t_bdl[1]:.3f}   CL {t_cl[0]:.3f}/{t_cl[1]:.3f}   SS2D {t_ss[0]:.3f}/{t_ss[1]:.3f}", flush=True)

@@ -27,3 +27,11 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     train_step(net, opt, lossf, x, y, ac); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70), flush=True)
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=70), flush=True)
+# pure host cost of one step: enqueue without waiting for the GPU in between
+torch.cuda.synchronize()
+ts = []
+for i in range(5):
+    t = time.perf_counter(); train_step(net, opt, lossf, x, y, ac); ts.append(time.perf_counter() - t)
+    torch.cuda.synchronize()
+log("host enqueue time per step (GPU idle at start): " + " ".join(f"{1e3 * v:.1f}" for v in ts) + " ms")

@@ -19,6 +19,6 @@ delta = (0.5 * torch.rand(4, bs, L, D, device=dev, generator=gen)).requires_grad
 gy = torch.randn(bs, L, D, device=dev, generator=gen)
 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 for i in range(iters):
-    e[0].record(); out = _SS2DScan.apply(xc, proj, delta, A, Dp, bias, Hh, Hh, N, R); e[1].record()
+    e[0].record(); out = _SS2DScan.apply(xc, proj, delta, None, A, Dp, bias, Hh, Hh, N, R); e[1].record()
     out.backward(gy); e[2].record(); torch.cuda.synchronize()
     print(f"iter {i}: fwd {e[0].elapsed_time(e[1]):.3f} ms  bwd {e[1].elapsed_time(e[2]):.3f} ms", flush=True)
