@@ -77,11 +77,12 @@ class _SplitHalves(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         half = x.shape[-1] // 2
+        ctx.dtype = x.dtype
         return x[..., :half], x[..., half:]
 
     @staticmethod
     def backward(ctx, dl, dr):
-        return torch.cat((dl.float(), dr.float()), dim=-1)
+        return torch.cat((dl.to(ctx.dtype), dr.to(ctx.dtype)), dim=-1)
 
 
 def split_halves(x):

@@ -218,7 +218,7 @@ class SS2D(nn.Module):
         _lib.require_cuda(x)
         B, H, W, C = x.shape
         xz = linear_splitk(x, self.in_proj.weight) if self.in_proj.bias is None else self.in_proj(x)
-        x, z = xz.chunk(2, dim=-1)                                  # (B,H,W,D) each, views of xz
+        x, z = split_halves(xz) if xz.is_cuda else xz.chunk(2, dim=-1)   # (B,H,W,D) views of xz; one concat in backward
         default_core = getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0
         if FUSED and default_core and self.d_conv == 3 and type(self.out_norm) is nn.LayerNorm and self.d_inner <= 1024:
             # channel-last fused core: the conv reads xz in place, the scan kernel applies the 4 direction maps itself,
