@@ -130,6 +130,54 @@ def _scan_orders(H, W, device):
     return idx, inv
 
 
+def ssd_scan_merge(mod, xc):
+    """Shared core of SS2D_with_SSD.forward (CNN_Mamba.py:494-552) and CrossMamba.forward.mamba_core
+    (CrossMamba_fusion_2b2.py:283-349): xc (B,H,W,conv_dim) = SiLU(dwconv([x | B | C | dt])) channel-last, fp32 ->
+    the four directions scanned and merged back to pixel order, (B,H,W,d_ssm) fp32.  `mod` supplies d_ssm, ngroups,
+    d_state, nheads, headdim, A_logs, Ds, dt_bias, D_has_hdim, chunk_size."""
+    B, H, W, conv_dim = xc.shape
+    L, K = H * W, 4
+    GN = mod.ngroups * mod.d_state
+    # 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
+    idx, inv = _scan_orders(H, W, xc.device)
+    xs4 = xc.reshape(B, L, conv_dim)[:, idx.reshape(-1)].view(B, K, L, conv_dim).transpose(1, 2)
+    xs, Bs, Cs, dts = torch.split(xs4, [mod.d_ssm, GN, GN, mod.nheads], dim=-1)
+    # layouts of CNN_Mamba.py:506-519: heads = (direction, head); B/C = the four directions' states concatenated
+    xs = xs.reshape(B, L, K * mod.nheads, mod.headdim)
+    dts = dts.reshape(B, L, K * mod.nheads)
+    Bs = Bs.reshape(B, L, mod.ngroups, -1)          # flat (k, g, n) order regrouped as "(g n)", as :517-519 does
+    Cs = Cs.reshape(B, L, mod.ngroups, -1)
+    As = -torch.exp(mod.A_logs.float())
+    Ds = mod.Ds.view(-1, mod.headdim) if mod.D_has_hdim else mod.Ds
+    y = mamba_chunk_scan_combined(xs.float(), dts.float(), As, Bs.float(), Cs.float(), chunk_size=mod.chunk_size,
+                                  D=Ds, z=None, dt_bias=mod.dt_bias.view(-1), dt_softplus=True)
+    y = y.reshape(B, L, K, mod.d_ssm)
+    assert y.dtype == torch.float
+    # cross-merge (CNN_Mamba.py:542-552): bring every direction back to pixel order and add, ((y1+y2)+y3)+y4
+    yk = [y[:, inv[k], k] for k in range(K)]
+    out = ((yk[0] + yk[2]) + yk[1]) + yk[3]
+    return out.view(B, H, W, -1)
+
+
+def ssd_tail(mod, out, z, z0, x0, d_mlp):
+    """RMSNormGated, optional gated-MLP concat, out_proj, dropout (CNN_Mamba.py:554-564)."""
+    if mod.rmsnorm:
+        out = mod.norm(out, z)
+    if d_mlp > 0:
+        out = torch.cat([F.silu(z0) * x0, out], dim=-1)
+    out_data = mod.out_proj(out)
+    if mod.dropout is not None:
+        out_data = mod.dropout(out_data)
+    return out_data
+
+
+def ssd_dwconv_silu(conv, x, d_conv):
+    """SiLU(depthwise conv(x)) on a channel-last (B,H,W,C) tensor (a view is fine) -> (B,H,W,C) fp32."""
+    if d_conv == 3:
+        return dwconv3x3_silu_nhwc(x, conv.weight, conv.bias)
+    return F.silu(conv(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1).float()
+
+
 class SS2D_with_SSD(nn.Module):
     """CNN_Mamba.py:322-564.  state_dict: in_proj.weight (2*d_inner + 2*G*N + nheads, d_model), conv2d.{weight
     (d_ssm+2GN+nheads,1,3,3), bias}, dt_bias (4,nheads), A_logs (4*nheads), Ds (4*nheads | 4*d_ssm), norm.weight (d_ssm),
@@ -210,38 +258,8 @@ class SS2D_with_SSD(nn.Module):
         z0, x0, z, xBCdt = torch.split(zxbcdt, [d_mlp, d_mlp, self.d_ssm, self.d_ssm + 2 * GN + self.nheads], dim=-1)
         # depthwise conv + SiLU over the whole [x | B | C | dt] stack (dt goes through the conv too, CNN_Mamba.py:490-491),
         # channel-last, reading zxbcdt in place
-        if self.d_conv == 3:
-            xc = dwconv3x3_silu_nhwc(xBCdt, self.conv2d.weight, self.conv2d.bias)              # (B,H,W,conv_dim) fp32
-        else:
-            xc = self.act(self.conv2d(xBCdt.permute(0, 3, 1, 2))).permute(0, 2, 3, 1).float()
-        conv_dim = xc.shape[-1]
-        # 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
-        idx, inv = _scan_orders(H, W, u.device)
-        xs4 = xc.reshape(B, L, conv_dim)[:, idx.reshape(-1)].view(B, K, L, conv_dim).transpose(1, 2)
-        xs, Bs, Cs, dts = torch.split(xs4, [self.d_ssm, GN, GN, self.nheads], dim=-1)
-        # layouts of CNN_Mamba.py:506-519: heads = (direction, head); B/C = the four directions' states concatenated
-        xs = xs.reshape(B, L, K * self.nheads, self.headdim)
-        dts = dts.reshape(B, L, K * self.nheads)
-        Bs = Bs.reshape(B, L, self.ngroups, -1)          # flat (k, g, n) order regrouped as "(g n)", as :517-519 does
-        Cs = Cs.reshape(B, L, self.ngroups, -1)
-        As = -torch.exp(self.A_logs.float())
-        Ds = self.Ds.view(-1, self.headdim) if self.D_has_hdim else self.Ds
-        y = mamba_chunk_scan_combined(xs.float(), dts.float(), As, Bs.float(), Cs.float(), chunk_size=self.chunk_size,
-                                      D=Ds, z=None, dt_bias=self.dt_bias.view(-1), dt_softplus=True)
-        y = y.reshape(B, L, K, self.d_ssm)
-        assert y.dtype == torch.float
-        # cross-merge (CNN_Mamba.py:542-552): bring every direction back to pixel order and add, ((y1+y2)+y3)+y4
-        yk = [y[:, inv[k], k] for k in range(K)]
-        out = ((yk[0] + yk[2]) + yk[1]) + yk[3]
-        out = out.view(B, H, W, -1)
-        if self.rmsnorm:
-            out = self.norm(out, z)
-        if d_mlp > 0:
-            out = torch.cat([F.silu(z0) * x0, out], dim=-1)
-        out_data = self.out_proj(out)
-        if self.dropout is not None:
-            out_data = self.dropout(out_data)
-        return out_data
+        xc = ssd_dwconv_silu(self.conv2d, xBCdt, self.d_conv)                                   # (B,H,W,conv_dim) fp32
+        return ssd_tail(self, ssd_scan_merge(self, xc), z, z0, x0, d_mlp)
 
 
 class SS_Conv_SSD(nn.Module):

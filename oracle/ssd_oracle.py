@@ -86,6 +86,52 @@ def ss2d_ssd_forward_oracle(mod, u):
     return F.linear(out, mod.out_proj.weight, mod.out_proj.bias)
 
 
+def _ssd_core_oracle(mod, xBCdt_nchw, z, z0, x0, d_mlp, B, H, W):
+    """The part SS2D_with_SSD.forward and CrossMamba.forward.mamba_core share, with the reference's tensor shuffles."""
+    L, K = H * W, 4
+    GN = mod.ngroups * mod.d_state
+    hwwh = torch.stack([xBCdt_nchw.reshape(B, -1, L), xBCdt_nchw.transpose(2, 3).reshape(B, -1, L)], dim=1)
+    xBCdts = torch.cat([hwwh, hwwh.flip(-1)], dim=1)
+    xs, Bs, Cs, dts = torch.split(xBCdts, [mod.d_ssm, GN, GN, mod.nheads], dim=2)
+    xs = xs.permute(0, 3, 1, 2).reshape(B, L, K * mod.nheads, mod.headdim)
+    dts = dts.permute(0, 3, 1, 2).reshape(B, L, K * mod.nheads)
+    Bs = Bs.reshape(B, -1, L).permute(0, 2, 1).reshape(B, L, mod.ngroups, -1)
+    Cs = Cs.reshape(B, -1, L).permute(0, 2, 1).reshape(B, L, mod.ngroups, -1)
+    As = -torch.exp(mod.A_logs.float())
+    Ds = mod.Ds.view(-1, mod.headdim) if mod.D_has_hdim else mod.Ds
+    y = ssd_scan_ref(xs.float(), dts.float(), As, Bs.float(), Cs.float(), D=Ds, dt_bias=mod.dt_bias.view(-1),
+                     dt_softplus=True)
+    out_y = y.reshape(B, L, K, -1).permute(0, 2, 3, 1)
+    inv_y = out_y[:, 2:4].flip(-1)
+    wh_y = out_y[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L)
+    invwh_y = inv_y[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L)
+    out = out_y[:, 0] + inv_y[:, 0] + wh_y + invwh_y
+    out = out.transpose(1, 2).reshape(B, H, W, -1)
+    if mod.rmsnorm:
+        out = rmsnorm_gated_ref(out, z, mod.norm.weight, eps=mod.norm.eps, norm_before_gate=mod.norm_before_gate).to(z.dtype)
+    if d_mlp > 0:
+        out = torch.cat([F.silu(z0) * x0, out], dim=-1)
+    return F.linear(out, mod.out_proj.weight, mod.out_proj.bias)
+
+
+def crossmamba_forward_oracle(mod, u1, u2, u2_cat_u1, u1_cat_u2):
+    """CrossMamba.forward (CrossMamba_fusion_2b2.py:235-385) on CPU tensors, op for op."""
+    B, H, W, _ = u1.shape
+
+    def dw(conv, t):
+        return F.silu(F.conv2d(t.permute(0, 3, 1, 2), conv.weight, conv.bias, padding=(mod.d_conv - 1) // 2, groups=t.shape[-1]))
+
+    def one(u, up):
+        zx = F.linear(u, mod.skip_in_proj.weight, mod.skip_in_proj.bias)
+        d_mlp = (zx.shape[-1] - mod.d_ssm) // 2
+        z0, x0, z = torch.split(zx, [d_mlp, d_mlp, mod.d_ssm], dim=-1)
+        xs = dw(mod.xs_conv2d, F.linear(u, mod.xs_in_proj.weight, mod.xs_in_proj.bias))
+        bcd = dw(mod.BCdts_conv2d, F.linear(up, mod.BCdts_in_proj.weight, mod.BCdts_in_proj.bias))
+        return _ssd_core_oracle(mod, torch.cat([xs, bcd], dim=1), z, z0, x0, d_mlp, B, H, W)
+
+    return one(u1, u2_cat_u1), one(u2, u1_cat_u2)
+
+
 def install_ssd(model):
     """Rebind every SS2D_with_SSD in `model` to the CPU restatement (CPU-side checker of the GPU modules)."""
     import types

@@ -139,3 +139,51 @@ def test_rmsnorm_gated_matches_restatement():
         x, z = torch.randn(3, 7, 48), torch.randn(3, 7, 48)
         want = ssd_oracle.rmsnorm_gated_ref(x, z, n.weight, 1e-5, nbg)
         np.testing.assert_allclose(n(x, z).detach().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_crossmamba_state_dict_surface_and_cpu_refusal():
+    """CrossMamba (CrossMamba_fusion_2b2.py:54-205): keys/shapes read off the constructor, incl. the two modules the
+    reference builds but never calls (in_proj, conv2d)."""
+    from medical_image_classification_amd.crossmamba import CrossMamba, MedSSD
+    from medical_image_classification_amd.cnn_mamba import SS2D_with_SSD
+    assert MedSSD is SS2D_with_SSD
+    d_model, d_state, headdim = 64, 16, 64
+    m = CrossMamba(d_model=d_model, d_state=d_state, headdim=headdim)
+    d_inner, nh, GN = 2 * d_model, 2 * d_model // headdim, d_state
+    want = {"dt_bias": (4, nh), "A_logs": (4 * nh,), "Ds": (4 * nh,),
+            "in_proj.weight": (2 * d_inner + 2 * GN + nh, d_model), "skip_in_proj.weight": (d_inner, d_model),
+            "xs_in_proj.weight": (d_inner, d_model), "BCdts_in_proj.weight": (2 * GN + nh, d_model),
+            "conv2d.weight": (d_inner + 2 * GN + nh, 1, 3, 3), "conv2d.bias": (d_inner + 2 * GN + nh,),
+            "xs_conv2d.weight": (d_inner, 1, 3, 3), "xs_conv2d.bias": (d_inner,),
+            "BCdts_conv2d.weight": (2 * GN + nh, 1, 3, 3), "BCdts_conv2d.bias": (2 * GN + nh,),
+            "norm.weight": (d_inner,), "out_proj.weight": (d_model, d_inner)}
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    u = [torch.randn(1, 3, 2, d_model) for _ in range(4)]
+    o1, o2 = ssd_oracle.crossmamba_forward_oracle(m, *u)
+    assert o1.shape == (1, 3, 2, d_model) and o2.shape == o1.shape and torch.isfinite(o1).all()
+    # the two outputs share weights but not inputs: swapping the modalities swaps the outputs
+    s2, s1 = ssd_oracle.crossmamba_forward_oracle(m, u[1], u[0], u[3], u[2])
+    assert torch.allclose(s1, o1) and torch.allclose(s2, o2)
+    with pytest.raises(RuntimeError):
+        m(*u)
+
+
+def test_checkpoint_formats_round_trip(tmp_path):
+    """The reference writes a bare state_dict (train.py:103) and {"epoch","model","optimizer","best_acc"}
+    (ddp_train.py:188-194); both load back through the safe loader into this package's modules."""
+    from medical_image_classification_amd.medmamba import VSSM
+    torch.manual_seed(0)
+    net = VSSM(depths=[1, 1], dims=[16, 32], num_classes=3)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    p1, p2 = tmp_path / "MedmambaNet.pth", tmp_path / "ddp.pth"
+    torch.save(net.state_dict(), p1)
+    torch.save({"epoch": 3, "model": net.state_dict(), "optimizer": opt.state_dict(), "best_acc": 0.5}, p2)
+    fresh = VSSM(depths=[1, 1], dims=[16, 32], num_classes=3)
+    fresh.load_state_dict(torch.load(p1, map_location="cpu", weights_only=True))
+    ck = torch.load(p2, map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model", "optimizer", "best_acc"}
+    fresh.load_state_dict(ck["model"])
+    for (k, a), (_, b) in zip(net.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    # a DDP-wrapped save carries the "module." prefix (ddp_train.py:188 saves model.module: no prefix) -- strip works
+    fresh.load_state_dict({k.removeprefix("module."): v for k, v in {"module." + k: v for k, v in ck["model"].items()}.items()})
