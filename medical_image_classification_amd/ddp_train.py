@@ -76,6 +76,7 @@ def main(argv=None):
     distributed, rank, world, local_rank = setup_distributed("nccl")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the dense-conv branch (perf only)
     net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
     start_epoch, best_acc = 0, 0.0
     optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)

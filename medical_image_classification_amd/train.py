@@ -56,6 +56,7 @@ def main(argv=None):
         raise RuntimeError("train.py needs an MI355X: the SS2D kernels have no CPU fallback")
     device = torch.device("cuda:0")
     print(f"using {device} device.")
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the dense-conv branch (perf only)
     net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
     loss_function = nn.CrossEntropyLoss()
     optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
