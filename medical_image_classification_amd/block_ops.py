@@ -23,11 +23,9 @@ class _LayerNormRows(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps, out_bf16):
         _lib.require_cuda(x, weight, bias)
         D = x.shape[-1]
-        if x.dtype != torch.float32:
-            x = x.float()
         ps = x.stride(-2) if x.dim() > 1 else D
-        # rows must be addressable as pixel * ps: unit channel stride and a uniform pixel stride over all leading dims
-        ok = x.stride(-1) == 1 and ps >= D
+        # rows must be addressable as pixel * ps: fp32, unit channel stride and a uniform pixel stride over all leading dims
+        ok = x.dtype == torch.float32 and x.stride(-1) == 1 and ps >= D
         if ok:
             exp = ps
             for d in range(x.dim() - 2, -1, -1):
@@ -36,7 +34,9 @@ class _LayerNormRows(torch.autograd.Function):
                     break
                 exp *= x.shape[d]
         if not ok:
-            x = x.contiguous(); ps = D
+            # one pass: cast + layout (Tensor.to ignores memory_format when the dtype already matches)
+            x = x.contiguous() if x.dtype == torch.float32 else x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            ps = D
         npix = x.numel() // D
         w = weight.detach().float().contiguous()
         b = bias.detach().float().contiguous()

@@ -67,6 +67,15 @@ class DropPath(nn.Module):
         return f"drop_prob={self.drop_prob}"
 
 
+def _norm_rows(norm, x, out_bf16=None):
+    """`norm(x)` through ms_layernorm_* when `norm` is a plain affine LayerNorm over the last axis of a CUDA tensor
+    (out_bf16=None: the ambient autocast dtype, for a LayerNorm that feeds a projection); the module itself otherwise."""
+    if BLOCK_FUSED and x.is_cuda and type(norm) is nn.LayerNorm and norm.elementwise_affine and norm.bias is not None \
+            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == x.shape[-1] <= 1024:
+        return layernorm_rows(x, norm.weight, norm.bias, norm.eps, out_bf16)
+    return norm(x)
+
+
 class PatchEmbed2D(nn.Module):
     """Image (B,C,H,W) -> tokens (B,H/p,W/p,embed_dim): strided conv + optional norm (MedMamba.py:146-169)."""
 
@@ -79,7 +88,7 @@ class PatchEmbed2D(nn.Module):
 
     def forward(self, x):
         x = self.proj(x).permute(0, 2, 3, 1)
-        return x if self.norm is None else self.norm(x)
+        return x if self.norm is None else _norm_rows(self.norm, x, out_bf16=False)
 
 
 class PatchMerging2D(nn.Module):
@@ -99,7 +108,7 @@ class PatchMerging2D(nn.Module):
         # order of the four taps as in the reference: (0,0), (1,0), (0,1), (1,1)
         taps = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
         x = torch.cat(taps, dim=-1).view(B, h2, w2, 4 * C)
-        return linear_splitk(self.norm(x), self.reduction.weight)
+        return linear_splitk(_norm_rows(self.norm, x), self.reduction.weight)     # LN lands in the GEMM's dtype
 
 
 class SS2D(nn.Module):

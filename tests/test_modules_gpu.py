@@ -404,3 +404,19 @@ def test_dtproj_kernels_vs_einsum(cfg):
     assert torch.equal(dproj[:, :, R:], torch.full_like(dproj[:, :, R:], 7.0))
     assert_close(dproj[:, :, :R], ddts.float().numpy(), 1e-4, 1e-5 * float(ddts.abs().max()), "ddts")
     assert_close(dWd, dW.float().numpy(), 1e-4, 2e-5 * float(dW.abs().max()), "dW")
+
+
+@pytest.mark.parametrize("case", ["permuted_fp32", "permuted_bf16", "contiguous_bf16"])
+def test_layernorm_rows_relayouts_unsuitable_inputs(case):
+    """Inputs the kernel cannot address in place (channel stride != 1, or not fp32) are re-laid out first -- the
+    PatchEmbed2D case: a conv output viewed as NHWC."""
+    from medical_image_classification_amd.block_ops import layernorm_rows
+    torch.manual_seed(2)
+    x = torch.randn(2, 16, 8, 8, device=dev())
+    if case.endswith("bf16"):
+        x = x.bfloat16()
+    x = x.permute(0, 2, 3, 1) if case.startswith("permuted") else x.permute(0, 2, 3, 1).contiguous()
+    w, b = torch.randn(16, device=dev()), torch.randn(16, device=dev())
+    y = layernorm_rows(x, w, b, 1e-5, False)
+    r = F.layer_norm(x.float(), (16,), w, b, 1e-5)
+    assert y.dtype == torch.float32 and float((y - r).abs().max()) < 1e-5
