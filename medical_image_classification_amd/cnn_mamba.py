@@ -67,7 +67,7 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt
     y = None
     for s0 in range(0, n, _STATE_SLICE):
         s1 = min(n, s0 + _STATE_SLICE)
-        yi = selective_scan_fn(u, delta, A_full.expand(dim, s1 - s0).contiguous(), Bt[:, :, s0:s1], Ct[:, :, s0:s1],
+        yi = selective_scan_fn(u, delta, A_full.expand(dim, s1 - s0), Bt[:, :, s0:s1], Ct[:, :, s0:s1],     # stride-0 states: scalar-decay kernels
                                Dc if s0 == 0 else None, None, bias, dt_softplus)
         y = yi if y is None else y + yi
     return y.transpose(1, 2).reshape(b, l, h, p).to(x.dtype)

@@ -24,7 +24,8 @@ namespace ms {
 
 constexpr int kWPB = 4;      // waves per workgroup in the backward: independent except for the per-chunk dB/dC combine
 
-template <int NPL, int CW, int MODE>
+// SA: scalar decay per channel (A_dstate_stride == 0, the SSD form): one exp2 and one stored decay per position.
+template <int NPL, int CW, int MODE, bool SA = false>
 __global__ void __launch_bounds__(64 * kWPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4;
@@ -83,7 +84,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int n = sg * NPL + i;
-        An[i] = n < N ? p.A[d * p.A_d_stride + n * p.A_dstate_stride] : 0.0f;
+        An[i] = (n < N || SA) ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] : 0.0f;
         A2[i] = An[i] * kLog2e;
         dhc[i] = 0.0f; dAacc[i] = 0.0f;
     }
@@ -171,7 +172,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 
         // ---- forward sweep: the decay a of EVERY position stays in registers (each exp2 is evaluated once per
         //      backward), h only at the start of every 4-position batch ------------------------------------
-        float av[kCL][NPL], ck[NB][NPL];
+        constexpr int NA = SA ? 1 : NPL;                       // decays stored per position
+        float av[kCL][NA], ck[NB][NPL];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int lb = kb * 4;
@@ -187,8 +189,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 const float du_ = dl_ * su[(lb + j) * kPitch + c];
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
-                    av[lb + j][i] = exp2_fast(dl_ * A2[i]);
-                    h[i] = fmaf(av[lb + j][i], h[i], du_ * Bv[i][j]);
+                    if (!SA || i == 0) av[lb + j][SA ? 0 : i] = exp2_fast(dl_ * A2[i]);
+                    h[i] = fmaf(av[lb + j][SA ? 0 : i], h[i], du_ * Bv[i][j]);
                 }
             }
         }
@@ -213,7 +215,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     bu[j][i] = du_ * Bv[i][j];
-                    hv[j][i] = fmaf(av[lb + j][i], j > 0 ? hv[j > 0 ? j - 1 : 0][i] : ck[kb][i], bu[j][i]);
+                    hv[j][i] = fmaf(av[lb + j][SA ? 0 : i], j > 0 ? hv[j > 0 ? j - 1 : 0][i] : ck[kb][i], bu[j][i]);
                 }
             }
             float duv[4], ddv[4], vB[4 * NPL], vC[4 * NPL];
@@ -231,7 +233,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     dAacc[i] = fmaf(qv, dl_[j], dAacc[i]);
                     vB[j * NPL + i] = dhn * du_;
                     vC[j * NPL + i] = gg[j] * hv[j][i];
-                    dhc[i] = av[lb + j][i] * dhn;
+                    dhc[i] = av[lb + j][SA ? 0 : i] * dhn;
                 }
                 duv[j] = fmaf(s1, dl_[j], Dv * gg[j]);               // du_l  = D g + delta' sum_n dh B
                 ddv[j] = fmaf(s1, uu[j], s2);                         // ddl_l = u sum_n dh B + sum_n dh A (a h_prev)
@@ -358,9 +360,13 @@ static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream
                        fits24(q.du_l_stride) && fits24(q.ddelta_l_stride) && fits24(p.B_l_stride) && fits24(p.C_l_stride) &&
                        fits24(q.dB_l_stride) && fits24(q.dC_l_stride);
     if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
+    const bool sa = p.A_dstate_stride == 0 && p.dstate > 1;
     switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
         case kModeSS2D: hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
-        case kModeCL:   hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
+        case kModeCL:
+            if (sa) hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL, true>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb);
+            else    hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb);
+            break;
         default:        hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
     }
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;

@@ -20,7 +20,9 @@ namespace ms {
 // wave whenever the waves drift further apart than the L2 can remember (measured: 3.7x over-fetch at stage 0 without).
 template <int CW> constexpr int fwd_waves() { return 32 / CW; }
 
-template <int NPL, int CW, int MODE>
+// SA ("scalar A"): every state of a channel shares one decay rate (A passed with A_dstate_stride == 0 -- the SSD /
+// Mamba-2 form, CNN_Mamba.py:514): a = exp2(delta' * A) is evaluated once per position instead of once per state.
+template <int NPL, int CW, int MODE, bool SA = false>
 __global__ void __launch_bounds__(64 * fwd_waves<CW>())
 scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, kWF = fwd_waves<CW>();
@@ -68,7 +70,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int n = sg * NPL + i;
-        A2[i] = n < N ? p.A[d * p.A_d_stride + n * p.A_dstate_stride] * kLog2e : 0.0f;
+        A2[i] = (n < N || SA) ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] * kLog2e : 0.0f;
         h[i] = 0.0f;
     }
     const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;   // the D*u term is added once, by group 0
@@ -119,13 +121,14 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
 
 #pragma unroll 2
         for (int lb = 0; lb < kCL; lb += 4) {
-            float dl_[4], du_[4], y[4];
+            float dl_[4], du_[4], y[4], aj[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 dl_[j] = sdl[(lb + j) * kPitch + c];
                 const float uu = su[(lb + j) * kPitch + c];
                 du_[j] = dl_[j] * uu;
                 y[j] = Dv * uu;
+                aj[j] = SA ? exp2_fast(dl_[j] * A2[0]) : 0.0f;
             }
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
@@ -134,7 +137,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
                 row4(sC + (sg * NPL + i) * kRowPitch, lb, Cv);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a = exp2_fast(dl_[j] * A2[i]);
+                    const float a = SA ? aj[j] : exp2_fast(dl_[j] * A2[i]);
                     h[i] = fmaf(a, h[i], du_[j] * Bv[j]);
                     y[j] = fmaf(Cv[j], h[i], y[j]);
                 }
@@ -192,9 +195,13 @@ static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
     const bool small = fits24(p.seqlen) && fits24(p.u_l_stride) && fits24(p.delta_l_stride) && fits24(p.out_l_stride) &&
                        fits24(p.B_l_stride) && fits24(p.C_l_stride);
     if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
+    const bool sa = p.A_dstate_stride == 0 && p.dstate > 1;     // scalar decay per channel (SSD form): channel-last variant only
     switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
         case kModeSS2D: hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb); break;
-        case kModeCL:   hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb); break;
+        case kModeCL:
+            if (sa) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL, true>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
+            else    hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
+            break;
         default:        hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeBDL>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb); break;
     }
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;

@@ -165,7 +165,9 @@ class SelectiveScanFn(torch.autograd.Function):
             G = max(Bg.shape[1], Cg.shape[1])
             Bg = Bg if Bg.shape[1] == G else Bg.repeat_interleave(G // Bg.shape[1], dim=1)
             Cg = Cg if Cg.shape[1] == G else Cg.repeat_interleave(G // Cg.shape[1], dim=1)
-        Af = A.contiguous()
+        # an A whose states are a stride-0 broadcast of one value per channel (SSD form) is passed through as is: the
+        # kernels then evaluate one decay per position instead of one per state
+        Af = A if (A.dim() == 2 and A.shape[1] > 1 and A.stride(1) == 0) else A.contiguous()
         Dc = D.contiguous() if D is not None else None
         bc = delta_bias.contiguous() if delta_bias is not None else None
         out = torch.empty_like(df)
@@ -209,7 +211,7 @@ class SelectiveScanFn(torch.autograd.Function):
         batch, dim, L = uf.shape
         N, G = Af.shape[1], Bg.shape[1]
         du, ddelta = torch.empty_like(uf), torch.empty_like(df)
-        dA = torch.zeros_like(Af)
+        dA = torch.zeros(Af.shape, device=Af.device, dtype=Af.dtype)       # dense even when Af is a broadcast view
         dB = torch.zeros((batch, G, N, L), device=uf.device, dtype=torch.float32)
         dC = torch.zeros_like(dB)
         dD = torch.zeros_like(Dc) if Dc is not None else None

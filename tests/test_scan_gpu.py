@@ -263,3 +263,36 @@ def test_long_sequence_medmamba_b_stage0():
     ref = so.scan_bwd(npy["u"], npy["delta"], npy["A"], npy["B"], npy["C"], npy["D"], None, npy["delta_bias"], g.numpy(), True)
     for k in ("u", "delta", "A", "B", "C", "D", "delta_bias"):
         assert relmax(t[k].grad, ref["d" + k]) < 2e-3, (k, relmax(t[k].grad, ref["d" + k]))
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 16, 100, 1), (1, 40, 12, 70, 2), (2, 64, 5, 33, 1), (1, 256, 16, 49, 4)])
+def test_scalar_decay_kernels_match_dense_A(cfg):
+    """A given as a stride-0 broadcast over the state axis (one decay rate per channel, the SSD / Mamba-2 form) takes the
+    scalar-decay kernel variants (one exp2 per position); results and every gradient must equal the dense-A kernels and
+    the oracle.  Channel-last activations, as cnn_mamba.mamba_chunk_scan_combined passes them."""
+    batch, dim, N, L, G = cfg
+    t_cpu, g = make_inputs(batch, dim, N, L, G, seed=21)
+    a_col = t_cpu["A"][:, :1].clone()                              # (dim, 1): one rate per channel
+    t_cpu["A"] = a_col.expand(dim, N).contiguous()
+    ref_out, _ = so.scan_fwd(*[t_cpu[k].numpy() for k in ("u", "delta", "A", "B", "C", "D")], None,
+                             t_cpu["delta_bias"].numpy(), True)
+    d = dev()
+    cl = lambda v: v.transpose(1, 2).contiguous().transpose(1, 2)   # (B,D,L) view of a channel-last tensor
+    res = {}
+    for mode in ("dense", "scalar"):
+        t = {k: v.to(d) for k, v in t_cpu.items()}
+        t["u"], t["delta"] = cl(t["u"]), cl(t["delta"])
+        col = a_col.to(d).requires_grad_()
+        t = {k: v.requires_grad_() for k, v in t.items() if k != "A"}
+        t["A"] = col.expand(dim, N) if mode == "scalar" else col.expand(dim, N).contiguous()
+        assert (t["A"].stride(1) == 0) == (mode == "scalar")
+        out, _ = run_hip(t, True)
+        out.backward(cl(g.to(d)))
+        res[mode] = (out.detach(), {k: v.grad for k, v in t.items() if k != "A"}, col.grad)
+    close(res["scalar"][0], ref_out, RTOL, ATOL, "out vs oracle")
+    assert torch.allclose(res["scalar"][0], res["dense"][0], rtol=1e-5, atol=1e-5)
+    for k in res["dense"][1]:
+        a, b = res["scalar"][1][k], res["dense"][1][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max()))), k
+    a, b = res["scalar"][2], res["dense"][2]
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * max(1.0, float(b.abs().max()))), "dA"
