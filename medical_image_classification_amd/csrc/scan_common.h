@@ -1,17 +1,18 @@
 // Shared device helpers for the gfx950 selective-scan kernels (wave64).
 //
-// Work mapping (DESIGN.md "Kernel design"):
+// Work mapping:
 //   * one WAVE = CW channels of one (batch, group) x all dstate states, CW = 16 or 8.  lane = sg*CW + c:
 //     c = lane % CW is the channel, sg = lane / CW one of SG = 64/CW state groups; a lane owns
 //     NPL = dstate/SG states of its channel.  (CW = 8 doubles the number of waves and halves the per-lane
-//     state: used when 16-channel waves would not fill the chip.)  The recurrence h_l = a_l*h_{l-1} + b_l runs sequentially IN REGISTERS
-//     along L -- no cross-lane scan; sums over the state axis are 2-step VALU exchanges
-//     (v_permlane32_swap / v_permlane16_swap), sums over the 16 channels are DPP row exchanges.
-//   * waves never talk to each other in the forward: every wave stages its own LDS tiles, so there is
-//     not a single s_barrier in the kernel and the hardware overlaps waves freely.
-//   * per chunk of MS_SCAN_CHUNK positions a wave stages u / delta' (/ dout) as [l][c] tiles (pitch 17)
-//     and the chunk's B/C rows as [n][l] (pitch 36: the 4 state groups hit disjoint bank quads), and
-//     prefetches the NEXT chunk into registers while computing the current one.
+//     state: used when 16-channel waves would not fill the chip, and always by the backward.)  The recurrence
+//     h_l = a_l*h_{l-1} + b_l runs sequentially IN REGISTERS along L -- no cross-lane scan; sums over the state axis
+//     are 2-3 step VALU exchanges (v_permlane32_swap / v_permlane16_swap / DPP); sums over the wave's channels
+//     (backward: dB, dC) go through a wave-private LDS transpose.
+//   * waves exchange no data in the forward.  A workgroup holds the waves whose channel blocks share a 128-byte
+//     line of the channel-last tensors and keeps them on the same chunk with one barrier (fetch each line once).
+//   * per chunk of MS_SCAN_CHUNK positions a wave stages u / delta' (/ dout) as [l][c] tiles (pitch CW+1)
+//     and the chunk's B/C rows as [n][l] (pitch 36: the state groups' ds_read_b128 hit disjoint bank quads),
+//     and prefetches the NEXT chunk into registers (use-free loads: nothing touches them until the next staging).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,7 +66,6 @@ struct PosMap {
     float invH;
     const int *tab;        // SS2D mode: LDS table of the current chunk's kCL positions (filled by fill_table)
     int tab_base;          // first sequence index the table covers
-    __device__ __forceinline__ int at(int l) const { return tab[l - tab_base]; }      // l inside the current chunk
     __device__ __forceinline__ void fill_table(int *t, int lbase, int lane) {
         if (lane < kCL) t[lane] = (*this)(min(lbase + lane, L - 1));
         tab = t; tab_base = lbase;
@@ -209,31 +209,6 @@ struct RowIO {
     __device__ __forceinline__ void put(float *s, const float (&r)[NE], int N, int len) const {
 #pragma unroll
         for (int k = 0; k < NE; ++k) s[nk(k) * kRowPitch + lk(k)] = (nk(k) < N && lk(k) < len) ? r[k] : 0.0f;
-    }
-    // SS2D mode: dB and dC of one pixel are adjacent in the projection-gradient row ([.. | B(N) | C(N)]), so both staged
-    // tiles are flushed together: lane idx -> (t = idx % 2NP, l = idx / 2NP), 2N*4-byte atomic segments per pixel.
-    __device__ __forceinline__ void flush_add_pair(const float *sB, const float *sC, float *baseB, int sl,
-                                                   const PosMap &pm, int N, int len) const {
-        char *b = reinterpret_cast<char *>(baseB);
-#pragma unroll
-        for (int k = 0; k < 2 * NE; ++k) {
-            const int idx = lane_ + 64 * k, t = idx % (2 * NP), l = idx / (2 * NP);
-            const bool isC = t >= NP;
-            const int n = isC ? t - NP : t;
-            if (n < N && l < len) {
-                const uint32_t off = (uint32_t)(__mul24(pm.tab[l], sl) + n + (isC ? N : 0)) * 4u;
-                atomicAdd(reinterpret_cast<float *>(b + off), (isC ? sC : sB)[n * kRowPitch + l]);
-            }
-        }
-    }
-    // accumulate a staged [n][l] tile into global memory (dB / dC of the backward)
-    __device__ __forceinline__ void flush_add(const float *s, float *base, int sn, int sl, int lbase,
-                                              const PosMap &pm, int N, int len) const {
-        char *b = reinterpret_cast<char *>(base);
-#pragma unroll
-        for (int k = 0; k < NE; ++k)
-            if (nk(k) < N && lk(k) < len)
-                atomicAdd(reinterpret_cast<float *>(b + goff(k, sn, sl, lbase, pm)), s[nk(k) * kRowPitch + lk(k)]);
     }
 };
 

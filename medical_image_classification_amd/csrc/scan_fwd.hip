@@ -5,9 +5,10 @@
 //   a      = exp2(delta' * A[d,n] * log2e)     b = delta' * u * B[b,g,n,l]
 //   h_l    = a*h_{l-1} + b                     y_l = sum_n C[b,g,n,l]*h_l + D[d]*u_l
 //
-// One wave = 16 channels x all states (scan_common.h): lane (sg, c) runs NPL states of channel c
-// sequentially in registers; the sum over the state axis is a 2-step permlane reduce-scatter per 4
-// positions.  No barriers, no cross-wave traffic; 1 workgroup = 1 wave.
+// One wave = CW channels x all states (scan_common.h): lane (sg, c) runs NPL states of channel c
+// sequentially in registers; the sum over the state axis is a 2-3 step permlane / DPP reduce-scatter per 4
+// positions.  No cross-wave traffic; a workgroup = the 2 (CW 16) or 4 (CW 8) waves whose channel blocks share a
+// 128-byte line, kept on the same chunk by one barrier.
 // Algorithmic traffic per (b,d,l): 12 B (u, delta in; out) + B/C rows (L2-served, shared by the waves of a
 // group) + dstate*4/32 B of saved state; no activation is read twice from HBM.
 #include "scan_common.h"
