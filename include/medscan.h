@@ -66,9 +66,14 @@ typedef enum MsStatus {
  *                   i.e. the cross-scan is folded into the kernel's addressing and the outputs come back in pixel
  *                   order, so the cross-merge (MedMamba.py:420-424,476) is a plain sum over the 4 groups.
  */
+/* bits of MsScanParams.delta_softplus */
+#define MS_SCAN_SOFTPLUS 1   /* delta' = softplus(delta + delta_bias) (selective_scan.h: delta_softplus) */
+#define MS_SCAN_A_IS_LOG 2   /* `A` holds A_log; the kernels use A = -exp(A_log) (what SS2D computes before every call,
+                                MedMamba.py:407) and the backward accumulates the gradient w.r.t. A_log in dA */
+
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;
-    int32_t delta_softplus;                 /* bool */
+    int32_t delta_softplus;                 /* flags: MS_SCAN_SOFTPLUS | MS_SCAN_A_IS_LOG (historically a bool: 1 = softplus) */
     int32_t map_h, map_w;
     int64_t u_batch_stride, u_group_stride, u_d_stride, u_l_stride;
     int64_t delta_batch_stride, delta_group_stride, delta_d_stride, delta_l_stride;

@@ -85,6 +85,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     for (int i = 0; i < NPL; ++i) {
         const int n = sg * NPL + i;
         An[i] = (n < N || SA) ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] : 0.0f;
+        if ((p.delta_softplus & MS_SCAN_A_IS_LOG) && (n < N || SA)) An[i] = -__expf(An[i]);
         A2[i] = An[i] * kLog2e;
         dhc[i] = 0.0f; dAacc[i] = 0.0f;
     }
@@ -105,7 +106,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     float *dBb = q.dB + b * q.dB_batch_stride + g * q.dB_group_stride;
     float *dCb = q.dC + b * q.dC_batch_stride + g * q.dC_group_stride;
-    const bool softplus = p.delta_softplus != 0;
+    const bool softplus = (p.delta_softplus & MS_SCAN_SOFTPLUS) != 0;
 
     // 32-bit copies of the strides the chunk loop needs (one SGPR each instead of slices of the 16-dword argument
     // tuples); channel-last and SS2D modes have unit channel / state strides (validated on the host)
@@ -313,7 +314,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const int n = sg * NPL + i;
-            if (n < N) atomicAdd(q.dA + (int64_t)d * N + n, dAacc[i]);
+            // A = -exp(A_log)  =>  dL/dA_log = dL/dA * A
+            if (n < N) atomicAdd(q.dA + (int64_t)d * N + n, (p.delta_softplus & MS_SCAN_A_IS_LOG) ? dAacc[i] * An[i] : dAacc[i]);
         }
     }
     // dD / ddelta_bias: every lane holds partial sums of the tile elements it staged / stored

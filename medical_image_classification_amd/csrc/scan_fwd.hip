@@ -71,7 +71,9 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int n = sg * NPL + i;
-        A2[i] = (n < N || SA) ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] * kLog2e : 0.0f;
+        float av = (n < N || SA) ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] : 0.0f;
+        if ((p.delta_softplus & MS_SCAN_A_IS_LOG) && (n < N || SA)) av = -__expf(av);
+        A2[i] = av * kLog2e;
         h[i] = 0.0f;
     }
     const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;   // the D*u term is added once, by group 0
@@ -87,7 +89,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     pm.tab = nullptr; pm.tab_base = 0;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
-    const bool softplus = p.delta_softplus != 0;
+    const bool softplus = (p.delta_softplus & MS_SCAN_SOFTPLUS) != 0;
 
     constexpr bool kGen = MODE == kModeBDL, kRowN = MODE == kModeSS2D;      // see scan_bwd.hip: 32-bit stride copies
     const int u_sd = kGen ? (int)p.u_d_stride : 1, u_sl = (int)p.u_l_stride;

@@ -66,11 +66,11 @@ def dwconv3x3_silu_nhwc(x, weight, bias):
     return _DWConvSiLUNHWC.apply(x, weight, bias)
 
 
-def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R):
+def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R, a_is_log=False):
     B, L, D = xc.shape[0], H * W, xc.shape[-1]
     C = R + 2 * N
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = B, 4 * D, L, N, 4
-    P.delta_softplus, P.map_h, P.map_w = 1, H, W
+    P.delta_softplus, P.map_h, P.map_w = 1 | (2 if a_is_log else 0), H, W      # MS_SCAN_SOFTPLUS | MS_SCAN_A_IS_LOG
     P.u_batch_stride, P.u_group_stride, P.u_d_stride, P.u_l_stride = L * D, 0, 1, D
     P.delta_batch_stride, P.delta_group_stride, P.delta_d_stride, P.delta_l_stride = L * D, B * L * D, 1, D
     P.out_batch_stride, P.out_group_stride, P.out_d_stride, P.out_l_stride = L * D, B * L * D, 1, D
@@ -178,6 +178,7 @@ class _SS2DScanNormGate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xc, proj, delta, wdt, A, Ds, dt_bias, z, gamma, beta, eps, H, W, N, R, out_bf16):
+        """`A` is A_logs (4D,N): the kernels apply A = -exp(A_logs) themselves and return d/dA_logs."""
         _lib.require_cuda(xc, proj, A, Ds, dt_bias, z, gamma, beta)
         lib = _lib.lib()
         B, D, L = xc.shape[0], xc.shape[-1], H * W
@@ -196,7 +197,7 @@ class _SS2DScanNormGate(torch.autograd.Function):
         x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=xc.device, dtype=torch.float32)
         out = torch.empty((B, H, W, D), device=xc.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         P = MsScanParams()
-        _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R)
+        _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R, a_is_log=True)
         stream = _lib.current_stream_ptr(xc.device)
         with torch.cuda.device(xc.device):
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
@@ -221,13 +222,15 @@ class _SS2DScanNormGate(torch.autograd.Function):
         dout = dout.contiguous()
         dy = torch.empty((B, L, D), device=xc.device, dtype=torch.float32)
         dz = torch.empty((B, H, W, D), device=xc.device, dtype=z.dtype)
-        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(beta)
         du4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
         ddelta = torch.empty_like(du4)
         dproj = torch.zeros_like(proj)
-        dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Ds), torch.zeros_like(dt_bias)
+        # the small accumulators share one zero-filled buffer (one fill launch instead of five)
+        sizes = (A.numel(), Ds.numel(), dt_bias.numel(), gamma.numel(), beta.numel())
+        zbuf = torch.zeros(sum(sizes), device=xc.device, dtype=torch.float32)
+        dA, dD, dbias, dgamma, dbeta = (t.view(r.shape) for t, r in zip(zbuf.split(sizes), (A, Ds, dt_bias, gamma, beta)))
         Q = MsScanBwdParams()
-        _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R)
+        _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R, a_is_log=True)
         Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
         Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, B * L * D, 1, D
         Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * D, B * L * D, 1, D
@@ -282,8 +285,9 @@ def ss2d_core_norm_gate(xc, z, mod):
     proj, delta, wdt = _projections(xc, mod.x_proj_weight, mod.dt_projs_weight, mod.d_state, mod.dt_rank)
     out_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
     with torch.autocast(device_type="cuda", enabled=False):
-        As = -torch.exp(mod.A_logs.float())
-        return _SS2DScanNormGate.apply(xc, proj, delta, wdt, As, mod.Ds.float().view(-1), mod.dt_projs_bias.float().view(-1),
+        # A = -exp(A_logs) (MedMamba.py:407) is formed inside the scan kernels (MS_SCAN_A_IS_LOG): no exp/neg launches,
+        # and the gradient comes back w.r.t. A_logs directly
+        return _SS2DScanNormGate.apply(xc, proj, delta, wdt, mod.A_logs.float(), mod.Ds.float().view(-1), mod.dt_projs_bias.float().view(-1),
                                        z, mod.out_norm.weight, mod.out_norm.bias, mod.out_norm.eps, H, W,
                                        mod.d_state, mod.dt_rank, out_bf16)
 
