@@ -177,6 +177,22 @@ int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_i
 int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
                       int64_t npix, int64_t pixels_per_sample, int C, void *stream);
 
+/* ---- training-mode BatchNorm2d (+ fused ReLU) of the conv branch (MedMamba.py:517-527, 533-535) ------------------
+ * x, y, dy, dx : (npix, C), unit channel stride = the memory of an NCHW tensor in channels_last format; bf16 or fp32.
+ * fwd: batch statistics (biased variance, fp32), y = [relu]((x - mean) * rstd * gamma + beta), running statistics
+ *      updated as torch does (unbiased variance, `momentum`), *num_batches_tracked += 1 when not NULL; save_mean /
+ *      save_rstd (C) are written for the backward.
+ * bwd: dgamma, dbeta (C) are WRITTEN; dx = gamma*rstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)), dy' = dy * [y > 0] when relu.
+ * `scratch`: ms_bn_scratch_floats(C) floats of workspace (per-workgroup partial sums; need not be initialised). */
+int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, const float *gamma, const float *beta, float *running_mean,
+                        float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int relu, void *y,
+                        int y_is_bf16, float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C,
+                        void *stream);
+int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
+                        const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
+                        float *scratch, int64_t npix, int C, void *stream);
+int ms_bn_scratch_floats(int C);
+
 /* ---- delta projection of SS2D (the `dt_projs` einsum, MedMamba.py:400,403-405) -------------------------------------
  * proj   (npix, 4, row_width) fp32: the x_proj output rows [dts(R) | B(N) | C(N)] of every (pixel, direction)
  * Wdt    (4, D, R) fp32 = dt_projs_weight;  delta / ddelta (4, npix, D) fp32;  R <= 32

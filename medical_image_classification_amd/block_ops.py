@@ -132,3 +132,86 @@ class _BlockTail(torch.autograd.Function):
 def block_tail(left, x, inp, sample_scale=None):
     """channel_shuffle(cat(left, sample_scale * x), groups=2) + inp for channel-last (B,H,W,C/2) halves and a (B,H,W,C) input."""
     return _BlockTail.apply(left, x, inp, sample_scale)
+
+
+# ---- training-mode BatchNorm2d (+ ReLU) of the conv branch, channels_last ---------------------------------------------
+_BN_SCRATCH = {}       # (device, C) -> workspace for the per-workgroup partial sums (stream-ordered reuse, never read stale)
+
+
+def _bn_scratch(device, C):
+    key = (device.index, C)
+    buf = _BN_SCRATCH.get(key)
+    if buf is None:
+        buf = _BN_SCRATCH[key] = torch.empty(_lib.lib().ms_bn_scratch_floats(C), device=device, dtype=torch.float32)
+    return buf
+
+
+def _nhwc_ok(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and t.dtype in (torch.float32, torch.bfloat16)
+
+
+class _BatchNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, out_bf16):
+        B, C, H, W = x.shape
+        npix = B * H * W
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.channels_last)
+        save = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_bn_relu_nhwc_fwd(
+                x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr(), running_mean.data_ptr(),
+                running_var.data_ptr(), nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), int(relu),
+                y.data_ptr(), int(out_bf16), save[0].data_ptr(), save[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(),
+                npix, C, _stream(x)), "ms_bn_relu_nhwc_fwd")
+        ctx.save_for_backward(x, w, b, save)
+        ctx.relu, ctx.wdtype, ctx.bdtype = bool(relu), weight.dtype, bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, save = ctx.saved_tensors
+        B, C, H, W = x.shape
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(dy, memory_format=torch.channels_last)
+        dgb = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ms_bn_relu_nhwc_bwd(
+                x.data_ptr(), int(x.dtype == torch.bfloat16), dy.data_ptr(), int(dy.dtype == torch.bfloat16), w.data_ptr(),
+                b.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), dx.data_ptr(), dgb[0].data_ptr(),
+                dgb[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(), B * H * W, C, _stream(x)), "ms_bn_relu_nhwc_bwd")
+        return dx.to(x.dtype), dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None, None, None, None, None, None
+
+
+def batchnorm_relu(bn, x, relu):
+    """`relu(bn(x))` (or `bn(x)`) for an nn.BatchNorm2d in TRAINING mode on a channels_last CUDA tensor, through
+    ms_bn_relu_nhwc_* (batch statistics, running-statistics update and num_batches_tracked as torch does).  Anything else
+    (eval mode, no affine / no running stats, cumulative momentum, other layouts) goes through the module itself."""
+    if not (bn.training and x.is_cuda and _nhwc_ok(x) and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and type(bn) is torch.nn.BatchNorm2d and bn.running_mean is not None):
+        y = bn(x)
+        return torch.relu(y) if relu else y
+    out_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+    return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                                bn.eps, relu, out_bf16)
+
+
+def conv_branch(seq, x):
+    """The conv branch of SS_Conv_SSM (`self.conv33conv33conv11`, MedMamba.py:517-527) applied module by module with each
+    BatchNorm2d (+ following ReLU) fused: BN -> conv3x3 -> BN+ReLU -> conv3x3 -> BN+ReLU -> conv1x1 -> ReLU.  Falls back to
+    `seq(x)` when the Sequential is not that exact pattern."""
+    mods = list(seq)
+    kinds = [type(m) for m in mods]
+    nn = torch.nn
+    if kinds != [nn.BatchNorm2d, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.ReLU]:
+        return seq(x)
+    x = batchnorm_relu(mods[0], x, False)
+    x = mods[1](x)
+    x = batchnorm_relu(mods[2], x, True)
+    x = mods[4](x)
+    x = batchnorm_relu(mods[5], x, True)
+    x = mods[7](x)
+    return mods[8](x)

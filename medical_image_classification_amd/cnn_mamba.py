@@ -28,7 +28,7 @@ import torch.utils.checkpoint as checkpoint
 
 from . import _lib
 from . import medmamba as mm
-from .block_ops import block_tail, layernorm_rows, split_halves
+from .block_ops import block_tail, conv_branch, layernorm_rows, split_halves
 from .medmamba import CONV_CHANNELS_LAST, DropPath, PatchEmbed2D, PatchMerging2D, channel_shuffle
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc
@@ -283,7 +283,7 @@ class SS_Conv_SSD(nn.Module):
                 and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
             left, right = split_halves(input)
             x = self.self_attention(layernorm_rows(right, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps))
-            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+            left = conv_branch(self.conv33conv33conv11, left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
             return block_tail(left.permute(0, 2, 3, 1), x, input, self.drop_path.sample_scale(x))
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))

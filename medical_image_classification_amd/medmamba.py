@@ -21,7 +21,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
-from .block_ops import block_tail, layernorm_rows, split_halves
+from .block_ops import block_tail, conv_branch, layernorm_rows, split_halves
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_splitk
@@ -295,7 +295,7 @@ class SS_Conv_SSM(nn.Module):
             # same arithmetic, fused around the SS2D path: in-place LayerNorm of the right half, one-pass tail
             left, right = split_halves(input)
             x = self.self_attention(layernorm_rows(right, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps))
-            left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+            left = conv_branch(self.conv33conv33conv11, left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
             return block_tail(left.permute(0, 2, 3, 1), x, input, self.drop_path.sample_scale(x))
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))

@@ -375,7 +375,9 @@ def test_fused_block_matches_unfused_block(monkeypatch):
     assert_close(dx1, dx0.cpu().numpy(), 1e-3, 1e-4 * float(dx0.abs().max()), "dx")
     for k in p0:
         r = p0[k].cpu().numpy()
-        assert_close(p1[k], r, 1e-2, max(1e-5, 1e-3 * float(np.abs(r).max())), k)
+        # conv biases in front of a BatchNorm have a mathematically zero gradient: both sides are ~1e-5 rounding noise
+        floor = 1e-4 if k.startswith("conv33conv33conv11") else 1e-5
+        assert_close(p1[k], r, 1e-2, max(floor, 1e-3 * float(np.abs(r).max())), k)
 
 
 @pytest.mark.parametrize("cfg", [(200, 96, 3, 35), (64, 192, 6, 38), (50, 384, 12, 44), (49, 768, 24, 56), (33, 70, 5, 37),
@@ -420,3 +422,66 @@ def test_layernorm_rows_relayouts_unsuitable_inputs(case):
     y = layernorm_rows(x, w, b, 1e-5, False)
     r = F.layer_norm(x.float(), (16,), w, b, 1e-5)
     assert y.dtype == torch.float32 and float((y - r).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(4, 48, 14, 14), (2, 96, 7, 9), (3, 384, 5, 5), (2, 20, 3, 4), (64, 48, 56, 56)])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_batchnorm_relu_kernels_vs_torch(cfg, relu, bf16):
+    """ms_bn_relu_nhwc_fwd/bwd vs torch BatchNorm2d(train) [+ ReLU] in float64: output, dx, dgamma, dbeta, running
+    statistics (unbiased variance, momentum) and num_batches_tracked."""
+    from medical_image_classification_amd.block_ops import batchnorm_relu
+    B, C, H, W = cfg
+    torch.manual_seed(13)
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev()).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.5 + 1); bn.bias.copy_(torch.randn(C) * 0.3)
+        bn.running_mean.copy_(torch.randn(C) * 0.2); bn.running_var.copy_(torch.rand(C) + 0.5)
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev()).double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    x = (torch.randn(B, C, H, W, device=dev()) * 1.5 + 0.7).contiguous(memory_format=torch.channels_last)
+    if bf16:
+        x = x.bfloat16()
+    g = torch.randn(B, C, H, W, device=dev()).contiguous(memory_format=torch.channels_last).to(x.dtype)
+    xd = x.clone().requires_grad_()
+    yd = batchnorm_relu(bn, xd, relu)
+    assert yd.dtype == x.dtype and yd.is_contiguous(memory_format=torch.channels_last)
+    yd.backward(g)
+    xr = x.double().requires_grad_()
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(g.double())
+    tol = 3e-2 if bf16 else 2e-4
+    sc = lambda t: max(1e-6, float(t.abs().max()))
+    assert float((yd.double() - yr).abs().max()) <= tol * sc(yr)
+    assert float((xd.grad.double() - xr.grad).abs().max()) <= tol * sc(xr.grad)
+    assert float((bn.weight.grad.double() - ref.weight.grad).abs().max()) <= tol * sc(ref.weight.grad)
+    assert float((bn.bias.grad.double() - ref.bias.grad).abs().max()) <= tol * sc(ref.bias.grad)
+    assert float((bn.running_mean.double() - ref.running_mean).abs().max()) <= 1e-4 * sc(ref.running_mean)
+    assert float((bn.running_var.double() - ref.running_var).abs().max()) <= 1e-4 * sc(ref.running_var)
+    assert int(bn.num_batches_tracked) == 1 == int(ref.num_batches_tracked)
+
+
+def test_conv_branch_fused_bn_matches_sequential():
+    """conv_branch(seq, x) == seq(x) for the conv33conv33conv11 Sequential (training mode): output, input gradient,
+    parameter gradients and BatchNorm buffers."""
+    from medical_image_classification_amd import medmamba as mm
+    from medical_image_classification_amd.block_ops import conv_branch
+    torch.manual_seed(17)
+    blk = mm.SS_Conv_SSM(hidden_dim=96, drop_path=0.0).to(dev()).train()
+    import copy
+    seq_a, seq_b = blk.conv33conv33conv11, copy.deepcopy(blk.conv33conv33conv11)
+    x = torch.randn(4, 48, 14, 14, device=dev()).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(4, 48, 14, 14, device=dev()).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = conv_branch(seq_a, xa); yb = seq_b(xb)
+    ya.backward(g); yb.backward(g)
+    assert_close(ya, yb.detach().cpu().numpy(), 1e-3, 1e-4 * float(yb.abs().max()), "y")
+    assert_close(xa.grad, xb.grad.cpu().numpy(), 1e-2, 1e-3 * float(xb.grad.abs().max()), "dx")
+    pb = dict(seq_b.named_parameters())
+    for k, p in seq_a.named_parameters():
+        r = pb[k].grad.cpu().numpy()
+        assert_close(p.grad, r, 5e-2, max(1e-4, 2e-3 * float(np.abs(r).max())), k)
+    bb = dict(seq_b.named_buffers())
+    for k, v in seq_a.named_buffers():
+        assert_close(v.float(), bb[k].float().cpu().numpy(), 1e-4, 1e-5, k)
