@@ -135,11 +135,11 @@ def block_tail(left, x, inp, sample_scale=None):
 
 
 # ---- training-mode BatchNorm2d (+ ReLU) of the conv branch, channels_last ---------------------------------------------
-_BN_SCRATCH = {}       # (device, C) -> workspace for the per-workgroup partial sums (stream-ordered reuse, never read stale)
+_BN_SCRATCH = {}       # (device, stream, C) -> workspace for the per-workgroup partial sums (reused in stream order)
 
 
 def _bn_scratch(device, C):
-    key = (device.index, C)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, C)
     buf = _BN_SCRATCH.get(key)
     if buf is None:
         buf = _BN_SCRATCH[key] = torch.empty(_lib.lib().ms_bn_scratch_floats(C), device=device, dtype=torch.float32)

@@ -84,20 +84,48 @@ def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R, a
     P.x = x_state.data_ptr()
 
 
+# dt_rank up to which ms_dtproj_* replace the batched GEMMs.  Measured (tools/bench_dtproj.py, MedMamba-T bs 64, fwd+bwd us):
+# R=3: 284 vs 438 (kernels win: K is too small for a GEMM); R=6: 201 vs 142; R=12: 207 vs 113; R=24: 312 vs 75 (few
+# pixels, wide K: a real GEMM).  The kernels tile R <= 32; the product path uses them where they win.
+_DT_KERNEL_MAX_RANK = 4
+
+
+def _split_k(M):
+    for cand in (64, 32, 16, 8, 4, 2):
+        if M % cand == 0 and M // cand >= 1024:
+            return cand
+    return 1
+
+
 def _dtproj_fwd(proj, wdt, B, L, D, R, C):
-    """delta (4,B,L,D) = dts @ Wdt^T with dts read in place from the projection rows (ms_dtproj_fwd)."""
-    delta = torch.empty((4, B, L, D), device=proj.device, dtype=torch.float32)
-    _lib.check(_lib.lib().ms_dtproj_fwd(proj.data_ptr(), wdt.data_ptr(), delta.data_ptr(), B * L, D, R, C,
-                                        _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd")
-    return delta
+    """delta (4,B,L,D) = dts @ Wdt^T (MedMamba.py:400), fp32, with dts = the first R columns of the projection rows:
+    ms_dtproj_fwd (reads them in place) for small ranks, one batched GEMM otherwise.  Runs inside the scan's autograd
+    node, so neither the dts slice nor delta ever becomes an autograd tensor."""
+    M = B * L
+    if R <= _DT_KERNEL_MAX_RANK:
+        delta = torch.empty((4, B, L, D), device=proj.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ms_dtproj_fwd(proj.data_ptr(), wdt.data_ptr(), delta.data_ptr(), M, D, R, C,
+                                            _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd")
+        return delta
+    dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                      # (4, M, R)
+    return torch.bmm(dts, wdt.transpose(1, 2)).view(4, B, L, D)
 
 
 def _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C):
-    """ddts into the first R columns of dproj (in place), returns dWdt (4,D,R)."""
-    dwdt = torch.zeros_like(wdt)
-    _lib.check(_lib.lib().ms_dtproj_bwd(ddelta.data_ptr(), proj.data_ptr(), wdt.data_ptr(), dproj.data_ptr(), dwdt.data_ptr(),
-                                        B * L, D, R, C, _lib.current_stream_ptr(proj.device)), "ms_dtproj_bwd")
-    return dwdt
+    """ddts into the first R columns of dproj (in place: the scan backward owns the B|C columns), returns dWdt (4,D,R).
+    The weight gradient reduces over M = B*L with a (D x R) output: split into slices, one batched GEMM, fp32 sum."""
+    M = B * L
+    if R <= _DT_KERNEL_MAX_RANK:
+        dwdt = torch.zeros_like(wdt)
+        _lib.check(_lib.lib().ms_dtproj_bwd(ddelta.data_ptr(), proj.data_ptr(), wdt.data_ptr(), dproj.data_ptr(), dwdt.data_ptr(),
+                                            M, D, R, C, _lib.current_stream_ptr(proj.device)), "ms_dtproj_bwd")
+        return dwdt
+    dd = ddelta.view(4, M, D)
+    dproj.view(M, 4, C)[:, :, :R].copy_(torch.bmm(dd, wdt).permute(1, 0, 2))
+    dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()
+    S = _split_k(M)
+    part = torch.bmm(dd.view(4 * S, M // S, D).transpose(1, 2), dts.view(4 * S, M // S, R))   # (4S, D, R)
+    return part.view(4, S, D, R).sum(dim=1)
 
 
 class _SS2DScan(torch.autograd.Function):
@@ -254,28 +282,16 @@ class _SS2DScanNormGate(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
-# dt_rank up to which ms_dtproj_* replace the batched GEMMs.  Measured (tools/bench_dtproj.py, MedMamba-T bs 64, fwd+bwd us):
-# R=3: 284 vs 438 (kernels win: K is too small for a GEMM); R=6: 201 vs 142; R=12: 207 vs 113; R=24: 312 vs 75 (few
-# pixels, wide K: a real GEMM).  The kernels tile R <= 32; the product path uses them where they win.
-_DT_KERNEL_MAX_RANK = 4
-
-
 def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):
     """x_proj follows the ambient autocast (bf16 under autocast, like the reference's einsum would, MedMamba.py:397);
-    dt_proj (K = R <= 32) is fp32 always (MedMamba.py:403-409) and runs inside the scan's autograd node (ms_dtproj_*);
-    returns (proj (B,L,4,C), delta or None, Wdt or None)."""
+    dt_proj is fp32 always (MedMamba.py:403-409) and runs inside the scan's autograd node (_dtproj_fwd/_dtproj_bwd);
+    returns (proj (B,L,4,C), None, Wdt)."""
     B, H, W, D = xc.shape
-    N, R = d_state, dt_rank
-    C = R + 2 * N
+    C = dt_rank + 2 * d_state
     M = B * H * W
-    from .ss2d_ops import dt_proj_splitk, linear_splitk
+    from .ss2d_ops import linear_splitk
     proj = linear_splitk(xc.view(M, D), x_proj_weight.view(4 * C, D)).float()               # (M, 4C)
-    if R <= _DT_KERNEL_MAX_RANK:
-        return proj.view(B, H * W, 4, C), None, dt_projs_weight
-    with torch.autocast(device_type="cuda", enabled=False):
-        dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                   # (4, M, R)
-        delta = dt_proj_splitk(dts, dt_projs_weight.float())                                # (4, M, D)
-    return proj.view(B, H * W, 4, C), delta.view(4, B, H * W, D), None
+    return proj.view(B, H * W, 4, C), None, dt_projs_weight
 
 
 def ss2d_core_norm_gate(xc, z, mod):

@@ -167,33 +167,3 @@ def linear_splitk(x, weight):
     if x.is_cuda and x.numel() // x.shape[-1] >= 8192:
         return _LinearSplitK.apply(x, weight)
     return torch.nn.functional.linear(x, weight)
-
-
-class _DtProjSplitK(torch.autograd.Function):
-    """delta[k] = dts[k] @ Wdt[k]^T for the 4 directions (MedMamba.py:400), fp32: dts (4,M,R), Wdt (4,D,R) -> (4,M,D).
-    The weight gradient dWdt[k] = ddelta[k]^T @ dts[k] reduces over M = B*H*W with a (D x R) output (R = 3..24): split
-    into S slices per direction, one batched GEMM, fp32 sum."""
-
-    @staticmethod
-    def forward(ctx, dts, wdt):
-        ctx.save_for_backward(dts, wdt)
-        return torch.bmm(dts, wdt.transpose(1, 2))
-
-    @staticmethod
-    def backward(ctx, dd):
-        dts, wdt = ctx.saved_tensors
-        K4, M, R = dts.shape
-        D = wdt.shape[1]
-        dd = dd.contiguous()
-        ddts = torch.bmm(dd, wdt) if ctx.needs_input_grad[0] else None            # (4, M, R)
-        S = 1
-        for cand in (64, 32, 16, 8, 4, 2):
-            if M % cand == 0 and M // cand >= 1024:
-                S = cand
-                break
-        part = torch.bmm(dd.view(K4 * S, M // S, D).transpose(1, 2), dts.view(K4 * S, M // S, R))   # (4S, D, R)
-        return ddts, part.view(K4, S, D, R).sum(dim=1)
-
-
-def dt_proj_splitk(dts, wdt):
-    return _DtProjSplitK.apply(dts, wdt)
