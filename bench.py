@@ -169,10 +169,13 @@ def main():
         torch.cuda.synchronize()
 
     log(f"model on {device}, world {world}; warm-up {args.warmup} steps")
+    from medical_image_classification_amd.medmamba import set_branch_streams
     for i in range(args.warmup):
         train_step(model, opt, lossf, images, labels, ac)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
+        if i == 0:
+            set_branch_streams(True)           # only if MEDSCAN_BRANCH_STREAMS=late|1 asks for two-stream blocks (opt-in)
     barrier()
     ssi.TIMER.enabled = True
     t0 = time.perf_counter()

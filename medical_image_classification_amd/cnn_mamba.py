@@ -281,10 +281,7 @@ class SS_Conv_SSD(nn.Module):
     def forward(self, input: torch.Tensor):
         if mm.BLOCK_FUSED and input.is_cuda and input.shape[-1] % 4 == 0 and type(self.ln_1) is nn.LayerNorm \
                 and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
-            left, right = split_halves(input)
-            x = self.self_attention(layernorm_rows(right, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps))
-            left = conv_branch(self.conv33conv33conv11, left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
-            return block_tail(left.permute(0, 2, 3, 1), x, input, self.drop_path.sample_scale(x))
+            return mm.fused_block_forward(self, input)
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))
         if CONV_CHANNELS_LAST and left.is_cuda:

@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
+from .medmamba import set_branch_streams
 from .train import build_model, synthetic_batch, train_step
 
 
@@ -94,6 +95,7 @@ def main(argv=None):
             images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
             running += train_step(ddp_net, optimizer, loss_function, images, labels,
                                   torch.bfloat16 if args.bf16 else None).item()
+            set_branch_streams(True)            # opt-in (MEDSCAN_BRANCH_STREAMS=late): two-stream blocks after the first step
         if rank == 0:
             print(f"[epoch {epoch + 1}] train_loss: {running / args.steps_per_epoch:.3f}")
             torch.save({"epoch": epoch, "model": net.state_dict(), "optimizer": optimizer.state_dict(),

@@ -34,6 +34,51 @@ FUSED = os.environ.get("MEDSCAN_FUSED", "1") != "0"
 CONV_CHANNELS_LAST = os.environ.get("MEDSCAN_CONV_CL", "1") == "1"
 # SS_Conv_SSM: in-place LayerNorm of the right half + one-pass cat/shuffle/drop-path/residual tail (block_ops.py)
 BLOCK_FUSED = os.environ.get("MEDSCAN_BLOCK_FUSED", "1") == "1"
+# SS_Conv_SSM: optionally run the conv branch on a side HIP stream, concurrently with the LayerNorm + SS2D branch (the
+# branches are independent until the tail).  OPT-IN: measured on MedMamba-T bs 64 it takes the step from 27.0 ms to
+# 24-25 ms in most processes but to 28-31 ms in others (same build, same box -- which hardware queue the side stream lands
+# on and how the per-stream allocator pools settle is not under our control), so the default stays single-stream.
+#   MEDSCAN_BRANCH_STREAMS=1     two streams from the first step
+#   MEDSCAN_BRANCH_STREAMS=late  the training drivers switch it on after their first step (set_branch_streams), once
+#                                MIOpen's find pass and the main-stream allocator pool are settled -- the better variant
+BRANCH_STREAMS = os.environ.get("MEDSCAN_BRANCH_STREAMS", "") == "1"
+_SIDE_STREAMS = {}
+
+
+def set_branch_streams(flag=True):
+    """Called by the training drivers after their first step: turns the two-stream blocks on when the user asked for
+    them with MEDSCAN_BRANCH_STREAMS=late (or =1); a no-op otherwise."""
+    global BRANCH_STREAMS
+    BRANCH_STREAMS = bool(flag) and os.environ.get("MEDSCAN_BRANCH_STREAMS", "") in ("1", "late")
+    return BRANCH_STREAMS
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device.index)
+    if s is None:
+        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def fused_block_forward(blk, input):
+    """Body of SS_Conv_SSM / SS_Conv_SSD.forward on the fused kernels (MedMamba.py:530-538): halves, in-place LayerNorm of
+    the right half -> self_attention, conv branch on the left half (optionally on a side stream: the branches are
+    independent until the tail), one-pass concat / shuffle / DropPath / residual tail."""
+    left, right = split_halves(input)
+    to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    if BRANCH_STREAMS:
+        cur = torch.cuda.current_stream(input.device)
+        side = _side_stream(input.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):           # autograd replays the same stream assignment in backward
+            left = conv_branch(blk.conv33conv33conv11, to_nchw(left))
+        x = blk.self_attention(layernorm_rows(right, blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps))
+        cur.wait_stream(side)
+        left.record_stream(cur)
+    else:
+        x = blk.self_attention(layernorm_rows(right, blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps))
+        left = conv_branch(blk.conv33conv33conv11, to_nchw(left))
+    return block_tail(left.permute(0, 2, 3, 1), x, input, blk.drop_path.sample_scale(x))
 
 
 class DropPath(nn.Module):
@@ -293,10 +338,7 @@ class SS_Conv_SSM(nn.Module):
         if BLOCK_FUSED and input.is_cuda and input.shape[-1] % 4 == 0 and type(self.ln_1) is nn.LayerNorm \
                 and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
             # same arithmetic, fused around the SS2D path: in-place LayerNorm of the right half, one-pass tail
-            left, right = split_halves(input)
-            x = self.self_attention(layernorm_rows(right, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps))
-            left = conv_branch(self.conv33conv33conv11, left.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
-            return block_tail(left.permute(0, 2, 3, 1), x, input, self.drop_path.sample_scale(x))
+            return fused_block_forward(self, input)
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))
         if CONV_CHANNELS_LAST and left.is_cuda:

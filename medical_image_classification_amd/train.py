@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .medmamba import VSSM as medmamba
+from .medmamba import set_branch_streams
 
 
 def synthetic_batch(batch_size, num_classes, res=224, device="cuda", generator=None):
@@ -69,6 +70,7 @@ def main(argv=None):
             images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
             loss = train_step(net, optimizer, loss_function, images, labels, torch.bfloat16 if args.bf16 else None)
             running_loss += loss.item()
+            set_branch_streams(True)            # opt-in (MEDSCAN_BRANCH_STREAMS=late): two-stream blocks after the first step
         dt = time.time() - t0
         net.eval()
         acc = 0

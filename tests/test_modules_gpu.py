@@ -485,3 +485,36 @@ def test_conv_branch_fused_bn_matches_sequential():
     bb = dict(seq_b.named_buffers())
     for k, v in seq_a.named_buffers():
         assert_close(v.float(), bb[k].float().cpu().numpy(), 1e-4, 1e-5, k)
+
+
+def test_two_stream_block_matches_single_stream():
+    """SS_Conv_SSM with the conv branch on a side HIP stream (set_branch_streams) == the single-stream block: same
+    output, input gradient and parameter gradients, over repeated steps (stream ordering bugs show up as stale reads)."""
+    from medical_image_classification_amd import medmamba as mm
+    torch.manual_seed(23)
+    blk = mm.SS_Conv_SSM(hidden_dim=96, drop_path=0.0).to(dev()).train()
+    x = torch.randn(8, 28, 28, 96, device=dev())
+    g = torch.randn(8, 28, 28, 96, device=dev())
+    res = {}
+    try:
+        for mode in (False, True):
+            mm.BRANCH_STREAMS = mode
+            outs = []
+            for it in range(3):
+                blk.zero_grad(set_to_none=True)
+                for m in blk.modules():
+                    if isinstance(m, torch.nn.BatchNorm2d):
+                        m.reset_running_stats()
+                xi = (x * (1.0 + 0.1 * it)).requires_grad_()
+                y = blk(xi)
+                y.backward(g)
+                torch.cuda.synchronize()
+                outs.append((y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+            res[mode] = outs
+    finally:
+        mm.BRANCH_STREAMS = False
+    for (y0, dx0, p0), (y1, dx1, p1) in zip(res[False], res[True]):
+        assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5 * float(y0.abs().max()))
+        assert torch.allclose(dx0, dx1, rtol=1e-4, atol=1e-5 * float(dx0.abs().max()))
+        for k in p0:
+            assert torch.allclose(p0[k], p1[k], rtol=1e-3, atol=max(1e-5, 1e-4 * float(p0[k].abs().max()))), k
