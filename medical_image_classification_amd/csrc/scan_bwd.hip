@@ -32,11 +32,11 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     constexpr int kRows = 4 * NPL * SG, kTP = CW + 4;      // transpose tile: rows x (CW + pad) floats, 16-byte aligned rows
     static_assert(kRows <= 64, "one lane per (position, state) of a batch");
     using Tile = TileIO<MODE, CW>;
-    using Rows = RowIO<MODE, NP>;
+    using Rows = RowIO<MODE, NP, kWPB>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     const MsScanParams &p = q.f;
-    __shared__ __attribute__((aligned(16))) float sB_[kWPB][NP * kRowPitch];
-    __shared__ __attribute__((aligned(16))) float sC_[kWPB][NP * kRowPitch];
+    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];          // B / C rows of the chunk: one copy per workgroup
+    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
     __shared__ __attribute__((aligned(16))) float sdB_[kWPB][NP * kRowPitch];   // this chunk's dB / dC of each wave's channels
     __shared__ __attribute__((aligned(16))) float sdC_[kWPB][NP * kRowPitch];
     __shared__ float su_[kWPB][kTile];       // u tile      -> du tile
@@ -48,7 +48,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     __shared__ int spos_[kWPB][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *sB = sB_[wv], *sC = sC_[wv], *sdB = sdB_[wv], *sdC = sdC_[wv];
+    float *sdB = sdB_[wv], *sdC = sdC_[wv];
     float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sTB = sTB_[wv], *sTC = sTC_[wv], *sbias = sbias_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
@@ -123,7 +123,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     const int dC_sn = kRowN ? 1 : (int)q.dC_dstate_stride, dC_sl = (int)q.dC_l_stride;
 
     const Tile tile(lane);
-    const Rows rows(lane);
+    const Rows rows(threadIdx.x);
     const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
     float ru[Tile::NE], rd[Tile::NE], rg[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     // dD = sum g*u and ddelta_bias = sum ddelta are accumulated by the lane that stages / stores the element
@@ -168,7 +168,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             const int n = sg * NPL + i;
             h[i] = (ch > 0 && n < N) ? rx[i] : 0.0f;
         }
-        wave_sync();
+        __syncthreads();                                   // the B/C tiles are staged by all waves of the workgroup
         if (ch > 0) fetch(ch - 1);                         // lands while this chunk is computed
 
         // ---- forward sweep: the decay a of EVERY position stays in registers (each exp2 is evaluated once per

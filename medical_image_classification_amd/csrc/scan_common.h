@@ -178,17 +178,21 @@ struct TileIO {
 };
 
 // The chunk's B (or C) rows: NP (padded) states x kCL positions, LDS layout [n][kRowPitch]; rows past the real
-// dstate and positions past `len` are zero.  Rows contiguous along L: lane owns position lane%32 of rows
-// lane/32 + 2k (128-byte segments).  SS2D mode (rows contiguous along n, one projection row per pixel): lane owns
-// element idx = lane + 64k, n = idx % NP, l = idx / NP (NP*4-byte segments).
-template <int MODE, int NP>
+// dstate and positions past `len` are zero.  The tile is SHARED by the NW waves of a workgroup (they serve the same
+// (batch, group), hence the same rows): thread tid owns elements idx = tid + 64*NW*k.  Rows contiguous along L:
+// l = idx % 32, n = idx / 32 (128-byte segments).  SS2D mode (rows contiguous along n, one projection row per pixel):
+// n = idx % NP, l = idx / NP (NP*4-byte segments).
+template <int MODE, int NP, int NW>
 struct RowIO {
     static constexpr bool NCONTIG = MODE == kModeSS2D;
-    static constexpr int NE = NP / 2;
-    int lane_;
-    __device__ __forceinline__ explicit RowIO(int lane) : lane_(lane) {}
-    __device__ __forceinline__ int nk(int k) const { return NCONTIG ? (lane_ + 64 * k) % NP : lane_ / kCL + 2 * k; }
-    __device__ __forceinline__ int lk(int k) const { return NCONTIG ? (lane_ + 64 * k) / NP : lane_ % kCL; }
+    static constexpr int NT = 64 * NW;                           // threads sharing the tile (the workgroup)
+    static constexpr int NE = (NP * kCL + NT - 1) / NT;          // elements per thread
+    int tid_;
+    __device__ __forceinline__ explicit RowIO(int tid) : tid_(tid) {}
+    __device__ __forceinline__ int idx(int k) const { return tid_ + NT * k; }
+    __device__ __forceinline__ bool in(int k) const { return (NP * kCL) % NT == 0 || idx(k) < NP * kCL; }
+    __device__ __forceinline__ int nk(int k) const { return NCONTIG ? idx(k) % NP : (idx(k) / kCL) % NP; }
+    __device__ __forceinline__ int lk(int k) const { return NCONTIG ? (idx(k) / NP) % kCL : idx(k) % kCL; }
     __device__ __forceinline__ uint32_t goff(int k, int sn, int sl, int lbase, const PosMap &pm) const {
         const int pos = NCONTIG ? pm.tab[lk(k)] : lbase + lk(k);
         return (uint32_t)(nk(k) * (NCONTIG ? 1 : sn) + pos_times<MODE != kModeBDL>(pos, sl)) * 4u;
@@ -204,11 +208,12 @@ struct RowIO {
         for (int k = 0; k < NE; ++k) off[k] = goff(k, sn, sl, lbase, pm);
 #pragma unroll
         for (int k = 0; k < NE; ++k)
-            r[k] = *reinterpret_cast<const float *>(b + ((nk(k) < N && lk(k) < len) ? off[k] : safe));
+            r[k] = *reinterpret_cast<const float *>(b + ((in(k) && nk(k) < N && lk(k) < len) ? off[k] : safe));
     }
     __device__ __forceinline__ void put(float *s, const float (&r)[NE], int N, int len) const {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) s[nk(k) * kRowPitch + lk(k)] = (nk(k) < N && lk(k) < len) ? r[k] : 0.0f;
+        for (int k = 0; k < NE; ++k)
+            if (in(k)) s[nk(k) * kRowPitch + lk(k)] = (nk(k) < N && lk(k) < len) ? r[k] : 0.0f;
     }
 };
 

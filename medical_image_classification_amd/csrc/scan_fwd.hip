@@ -16,9 +16,10 @@
 namespace ms {
 
 // Waves per workgroup in the forward: the waves of a workgroup own ADJACENT channel blocks, together one 128-byte line
-// per position of the channel-last tensors (CW * 4 B * kWF = 128), and meet at one barrier per chunk.  They never
-// exchange data: the barrier only keeps them on the same chunk, so a line is fetched from HBM once instead of once per
-// wave whenever the waves drift further apart than the L2 can remember (measured: 3.7x over-fetch at stage 0 without).
+// per position of the channel-last tensors (CW * 4 B * kWF = 128).  They share the chunk's B/C tiles (same batch and
+// group) and meet at two barriers per chunk, which also keeps them on the same chunk, so a line is fetched from HBM once
+// instead of once per wave whenever the waves drift further apart than the L2 can remember (measured: 3.7x over-fetch
+// at stage 0 without).
 template <int CW> constexpr int fwd_waves() { return 32 / CW; }
 
 // SA ("scalar A"): every state of a channel shares one decay rate (A passed with A_dstate_stride == 0 -- the SSD /
@@ -29,16 +30,16 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, kWF = fwd_waves<CW>();
     using Tile = TileIO<MODE, CW>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
-    using Rows = RowIO<MODE, NP>;
-    __shared__ __attribute__((aligned(16))) float sB_[kWF][NP * kRowPitch];
-    __shared__ __attribute__((aligned(16))) float sC_[kWF][NP * kRowPitch];
+    using Rows = RowIO<MODE, NP, fwd_waves<CW>()>;
+    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];          // B / C rows of the chunk: one copy per workgroup
+    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
     __shared__ float su_[kWF][kTile];       // u tile, overwritten in place by the out tile
     __shared__ float sdl_[kWF][kTile];      // delta' tile
     __shared__ float sbias_[kWF][kCW];
     __shared__ int spos_[kWF][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *sB = sB_[wv], *sC = sC_[wv], *su = su_[wv], *sdl = sdl_[wv], *sbias = sbias_[wv];
+    float *su = su_[wv], *sdl = sdl_[wv], *sbias = sbias_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
 
@@ -98,7 +99,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const int B_sn = kRowN ? 1 : (int)p.B_dstate_stride, B_sl = (int)p.B_l_stride;
     const int C_sn = kRowN ? 1 : (int)p.C_dstate_stride, C_sl = (int)p.C_l_stride;
     const Tile tile(lane);
-    const Rows rows(lane);
+    const Rows rows(threadIdx.x);
     const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
     float ru[Tile::NE], rd[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     auto fetch = [&](int ch) {
@@ -114,12 +115,12 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
 
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        if (kWF > 1) __syncthreads();                       // lockstep only (see fwd_waves)
+        __syncthreads();                                    // everyone is done with the previous chunk's shared B/C tiles
         tile.put(su, ru, nvalid, len);
         tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
         rows.put(sB, rB, N, len);
         rows.put(sC, rC, N, len);
-        wave_sync();
+        __syncthreads();                                    // the B/C tiles are staged by all waves of the workgroup
         if (ch + 1 < n_chunks) fetch(ch + 1);              // lands while this chunk is computed
 
 #pragma unroll 2
