@@ -55,7 +55,9 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     // transpose-reduce ownership: lane rr sums row rr = (j*NPL + i)*SG + sg' -> position lb + j, state sg'*NPL + i
     const int t_out = ((lane % SG) * NPL + (lane / SG) % NPL) * kRowPitch + lane / (NPL * SG);
 
-    const int N = p.dstate, L = p.seqlen;
+    // scalars used inside the chunk loop are copied out of the 8-dword argument tuples (readfirstlane makes a fresh
+    // SGPR): when the register allocator spills them it then reloads ONE lane instead of the whole tuple
+    const int N = __builtin_amdgcn_readfirstlane(p.dstate), L = __builtin_amdgcn_readfirstlane(p.seqlen);
     const int dpg = p.dim / p.n_groups;
     // workgroup -> (batch, group, channel block).  Workgroups are dealt round-robin over the 8 XCDs, so the
     // waves that share one (batch, group)'s B/C rows are given equal blockIdx % 8: they hit one XCD's L2
@@ -99,7 +101,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float *dub = q.du + b * q.du_batch_stride + g * q.du_group_stride + c0w * q.du_d_stride;
     float *ddb = q.ddelta + b * q.ddelta_batch_stride + g * q.ddelta_group_stride + c0w * q.ddelta_d_stride;
     PosMap pm;
-    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.H = p.map_h; pm.W = p.map_w; pm.L = L;
+    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.L = L;
+    pm.H = __builtin_amdgcn_readfirstlane(p.map_h); pm.W = __builtin_amdgcn_readfirstlane(p.map_w);
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     pm.tab = nullptr; pm.tab_base = 0;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
@@ -132,18 +135,20 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 #pragma unroll
     for (int k = 0; k < Tile::NA; ++k) { dDk[k] = 0.0f; dbk[k] = 0.0f; }
     float rx[NPL];          // saved state at the start of the prefetched chunk (x[b, ch-1]); zero for the first chunk
+    const float *xs0[NPL];  // &x[b, 0, n_i, d] (or a dummy valid word when single-chunk sequences carry no saved states)
+    const int64_t x_chunk_stride = n_chunks > 1 ? (int64_t)N * p.dim : 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = min(sg * NPL + i, N - 1);
+        xs0[i] = n_chunks > 1 ? p.x + ((int64_t)b * n_chunks * N + n) * p.dim + d : p.A;
+    }
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
         // the state load goes out with (and is waited for with) the tile loads: a load consumed inside the sweeps would
         // put an s_waitcnt vmcnt(0) there and expose the whole prefetch
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            const int n = min(sg * NPL + i, N - 1);
-            // single-chunk sequences have no saved states (x may be null): read a dummy valid word instead of branching
-            const float *xs = n_chunks > 1 ? p.x + (((int64_t)b * n_chunks + max(ch - 1, 0)) * N + n) * p.dim + d : p.A;
-            rx[i] = *xs;
-        }
+        for (int i = 0; i < NPL; ++i) rx[i] = xs0[i][(int64_t)max(ch - 1, 0) * x_chunk_stride];
         tile.fetch(ru, ub, u_sd, u_sl, l0, pm, nvalid, len);
         tile.fetch(rd, db, dl_sd, dl_sl, l0, pm, nvalid, len);
         tile.fetch(rg, gb, g_sd, g_sl, l0, pm, nvalid, len);

@@ -43,7 +43,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
 
-    const int N = p.dstate, L = p.seqlen;
+    const int N = __builtin_amdgcn_readfirstlane(p.dstate), L = __builtin_amdgcn_readfirstlane(p.seqlen);   // see scan_bwd.hip
     const int dpg = p.dim / p.n_groups;
     // workgroup -> (batch, group, channel block).  Workgroups are dealt round-robin over the 8 XCDs, so the
     // waves that share one (batch, group)'s B/C rows are given equal blockIdx % 8: they hit one XCD's L2
@@ -85,7 +85,8 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const float *db = p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0w * p.delta_d_stride;
     float *ob = p.out + b * p.out_batch_stride + g * p.out_group_stride + c0w * p.out_d_stride;
     PosMap pm;
-    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.H = p.map_h; pm.W = p.map_w; pm.L = L;
+    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.L = L;
+    pm.H = __builtin_amdgcn_readfirstlane(p.map_h); pm.W = __builtin_amdgcn_readfirstlane(p.map_w);
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     pm.tab = nullptr; pm.tab_base = 0;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
