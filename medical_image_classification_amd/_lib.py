@@ -121,8 +121,29 @@ def check(status, what):
 
 
 def current_stream_ptr(device):
+    """HIP stream the kernels are enqueued on: torch's current stream of `device` (raw handle, no Stream object)."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device()))
+
+
+class on_device:
+    """`with on_device(dev):` -- torch.cuda.device(dev) only when `dev` is not already the current device (the common
+    single-GPU-per-process case costs one integer compare instead of two driver calls)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        import torch
+        idx = device.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def require_cuda(*tensors):

@@ -41,7 +41,7 @@ class _LayerNormRows(torch.autograd.Function):
         w = weight.detach().float().contiguous()
         b = bias.detach().float().contiguous()
         out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_layernorm_fwd(x.data_ptr(), ps, w.data_ptr(), b.data_ptr(), float(eps), out.data_ptr(),
                                                    int(out_bf16), npix, D, _stream(x)), "ms_layernorm_fwd")
         ctx.save_for_backward(x, w)
@@ -58,7 +58,7 @@ class _LayerNormRows(torch.autograd.Function):
         dout = dout.contiguous()
         dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         dgb = torch.zeros((2, D), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_layernorm_bwd(x.data_ptr(), ctx.ps, w.data_ptr(), ctx.eps, dout.data_ptr(),
                                                    int(dout.dtype == torch.bfloat16), dx.data_ptr(), dgb[0].data_ptr(),
                                                    dgb[1].data_ptr(), npix, D, _stream(x)), "ms_layernorm_bwd")
@@ -107,7 +107,7 @@ class _BlockTail(torch.autograd.Function):
         if sc is not None and sc.numel() != B:
             raise RuntimeError("block_tail: sample_scale must have one entry per sample")
         out = torch.empty_like(inp)
-        with torch.cuda.device(inp.device):
+        with _lib.on_device(inp.device):
             _lib.check(_lib.lib().ms_block_tail_fwd(left.data_ptr(), int(left.dtype == torch.bfloat16), x.data_ptr(),
                                                     int(x.dtype == torch.bfloat16), inp.data_ptr(),
                                                     sc.data_ptr() if sc is not None else None, out.data_ptr(),
@@ -122,7 +122,7 @@ class _BlockTail(torch.autograd.Function):
         dl = torch.empty((B, H, W, C // 2), device=dout.device, dtype=ctx.ldt)
         dx = torch.empty((B, H, W, C // 2), device=dout.device, dtype=ctx.xdt)
         sc = ctx.scale
-        with torch.cuda.device(dout.device):
+        with _lib.on_device(dout.device):
             _lib.check(_lib.lib().ms_block_tail_bwd(dout.data_ptr(), sc.data_ptr() if sc is not None else None, dl.data_ptr(),
                                                     int(ctx.ldt == torch.bfloat16), dx.data_ptr(), int(ctx.xdt == torch.bfloat16),
                                                     B * H * W, H * W, C, _stream(dout)), "ms_block_tail_bwd")
@@ -159,7 +159,7 @@ class _BatchNormReLU(torch.autograd.Function):
         b = bias.detach().float().contiguous()
         y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.channels_last)
         save = torch.empty((2, C), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_bn_relu_nhwc_fwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr(), running_mean.data_ptr(),
                 running_var.data_ptr(), nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), int(relu),
@@ -178,7 +178,7 @@ class _BatchNormReLU(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(dy, memory_format=torch.channels_last)
         dgb = torch.empty((2, C), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_bn_relu_nhwc_bwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), dy.data_ptr(), int(dy.dtype == torch.bfloat16), w.data_ptr(),
                 b.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), dx.data_ptr(), dgb[0].data_ptr(),

@@ -17,7 +17,7 @@ import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
 from .medmamba import set_branch_streams
-from .train import build_model, synthetic_batch, train_step
+from .train import build_model, make_adam, synthetic_batch, train_step
 
 
 def setup_distributed(backend=None):
@@ -77,10 +77,9 @@ def main(argv=None):
     distributed, rank, world, local_rank = setup_distributed("nccl")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the dense-conv branch (perf only)
     net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
     start_epoch, best_acc = 0, 0.0
-    optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
+    optimizer = make_adam(net.parameters(), lr=0.0001)
     if args.resume:
         ckpt = torch.load(args.resume, map_location=device, weights_only=True)
         net.load_state_dict(ckpt["model"]); optimizer.load_state_dict(ckpt["optimizer"])

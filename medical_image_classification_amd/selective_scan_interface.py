@@ -176,7 +176,7 @@ class SelectiveScanFn(torch.autograd.Function):
         if batch > 0 and L > 0:
             P = MsScanParams()
             _fill_fwd(P, uf, df, Af, Bg, Cg, Dc, bc, out, x, delta_softplus)
-            with torch.cuda.device(u.device):
+            with _lib.on_device(u.device):
                 rc = TIMER.launch("scan_fwd", algorithmic_bytes(batch, dim, L, N, Bg.shape[1], False), u.device,
                                   lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(u.device)))
                 _lib.check(rc, "ms_selective_scan_fwd")
@@ -229,7 +229,7 @@ class SelectiveScanFn(torch.autograd.Function):
             Q.dA, Q.dB, Q.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
             Q.dD = dD.data_ptr() if dD is not None else None
             Q.ddelta_bias = dbias.data_ptr() if dbias is not None else None
-            with torch.cuda.device(uf.device):
+            with _lib.on_device(uf.device):
                 rc = TIMER.launch("scan_bwd", algorithmic_bytes(batch, dim, L, N, G, True), uf.device,
                                   lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(uf.device)))
                 _lib.check(rc, "ms_selective_scan_bwd")

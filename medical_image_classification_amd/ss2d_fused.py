@@ -36,7 +36,7 @@ class _DWConvSiLUNHWC(torch.autograd.Function):
         w = weight.detach().float().contiguous()
         b = bias.detach().float().contiguous() if bias is not None else None
         y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_fwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr() if b is not None else None,
                 y.data_ptr(), B, C, H, W, ps, _lib.current_stream_ptr(x.device)), "ms_dwconv3x3_silu_nhwc_fwd")
@@ -53,7 +53,7 @@ class _DWConvSiLUNHWC(torch.autograd.Function):
         scratch = torch.empty_like(dx)
         dw = torch.zeros_like(w)
         db = torch.zeros_like(b) if b is not None else None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr() if b is not None else None,
                 dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
@@ -140,7 +140,7 @@ class _SS2DScan(torch.autograd.Function):
         xc, proj = xc.contiguous(), proj.contiguous()
         A, Ds, dt_bias = A.contiguous(), Ds.contiguous(), dt_bias.contiguous()
         ctx.has_wdt = wdt is not None
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             if ctx.has_wdt:
                 wdt = wdt.detach().float().contiguous()
                 delta = _dtproj_fwd(proj, wdt, B, L, D, R, R + 2 * N)
@@ -150,7 +150,7 @@ class _SS2DScan(torch.autograd.Function):
         x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=xc.device, dtype=torch.float32)
         P = MsScanParams()
         _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R)
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
                               lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(xc.device)))
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
@@ -180,7 +180,7 @@ class _SS2DScan(torch.autograd.Function):
         Q.dout, Q.du, Q.ddelta = dy.data_ptr(), du4.data_ptr(), ddelta.data_ptr()
         Q.dA, Q.dD, Q.ddelta_bias = dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
         Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), xc.device,
                               lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(xc.device)))
             _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
@@ -213,7 +213,7 @@ class _SS2DScanNormGate(torch.autograd.Function):
         xc, proj = xc.contiguous(), proj.contiguous()
         A, Ds, dt_bias = A.contiguous(), Ds.contiguous(), dt_bias.contiguous()
         ctx.has_wdt = wdt is not None
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             if ctx.has_wdt:
                 wdt = wdt.detach().float().contiguous()
                 delta = _dtproj_fwd(proj, wdt, B, L, D, R, R + 2 * N)
@@ -227,7 +227,7 @@ class _SS2DScanNormGate(torch.autograd.Function):
         P = MsScanParams()
         _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R, a_is_log=True)
         stream = _lib.current_stream_ptr(xc.device)
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
                               lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
@@ -268,7 +268,7 @@ class _SS2DScanNormGate(torch.autograd.Function):
         Q.dA, Q.dD, Q.ddelta_bias = dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
         Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
         stream = _lib.current_stream_ptr(xc.device)
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             _lib.check(lib.ms_ln_gate_bwd(y4.data_ptr(), B * L * D, z.data_ptr(), int(z.dtype == torch.bfloat16), zps,
                                           gamma.data_ptr(), beta.data_ptr(), eps, dout.data_ptr(),
                                           int(dout.dtype == torch.bfloat16), dy.data_ptr(), dz.data_ptr(),

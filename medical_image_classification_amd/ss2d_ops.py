@@ -25,7 +25,7 @@ class _CrossScan(torch.autograd.Function):
         x = x.contiguous()
         xs = torch.empty((B, 4, D, H * W), device=x.device, dtype=torch.float32)
         ctx.hw = (H, W)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_cross_scan(x.data_ptr(), xs.data_ptr(), B, D, H, W, _stream(x)), "ms_cross_scan")
         return xs
 
@@ -36,7 +36,7 @@ class _CrossScan(torch.autograd.Function):
         B, _, D, L = g.shape
         g = g.contiguous().float()
         dx = torch.empty((B, D, H, W), device=g.device, dtype=torch.float32)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.lib().ms_cross_merge(g.data_ptr(), dx.data_ptr(), B, D, H, W, _stream(g)), "ms_cross_merge")
         return dx
 
@@ -52,7 +52,7 @@ class _CrossMerge(torch.autograd.Function):
         ys = ys.contiguous()
         y = torch.empty((B, D, L), device=ys.device, dtype=torch.float32)
         ctx.hw = (H, W)
-        with torch.cuda.device(ys.device):
+        with _lib.on_device(ys.device):
             _lib.check(_lib.lib().ms_cross_merge(ys.data_ptr(), y.data_ptr(), B, D, H, W, _stream(ys)), "ms_cross_merge")
         return y
 
@@ -63,7 +63,7 @@ class _CrossMerge(torch.autograd.Function):
         B, D, L = g.shape
         g = g.contiguous().float()
         dys = torch.empty((B, 4, D, L), device=g.device, dtype=torch.float32)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.lib().ms_cross_scan(g.data_ptr(), dys.data_ptr(), B, D, H, W, _stream(g)), "ms_cross_scan")
         return dys, None, None
 
@@ -79,7 +79,7 @@ class _DWConvSiLU(torch.autograd.Function):
         x, weight = x.contiguous(), weight.contiguous()
         bias = bias.contiguous() if bias is not None else None
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_dwconv3x3_silu_fwd(x.data_ptr(), weight.data_ptr(),
                                                        bias.data_ptr() if bias is not None else None,
                                                        y.data_ptr(), B, C, H, W, _stream(x)), "ms_dwconv3x3_silu_fwd")
@@ -95,7 +95,7 @@ class _DWConvSiLU(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.zeros_like(weight)
         db = torch.zeros_like(bias) if bias is not None else None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_dwconv3x3_silu_bwd(x.data_ptr(), weight.data_ptr(),
                                                        bias.data_ptr() if bias is not None else None,
                                                        dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),

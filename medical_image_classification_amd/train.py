@@ -28,6 +28,18 @@ def build_model(num_classes=8, variant="T", **kw):
     return medmamba(num_classes=num_classes, **kw)
 
 
+def make_adam(params, lr=0.0001):
+    """`optim.Adam(net.parameters(), lr=0.0001)` of the reference (train.py:62).  On the GPU the fused (single multi-tensor
+    kernel) implementation is used when this torch build has it: same update rule, ~30 fewer launches per step."""
+    params = list(params)
+    if params and all(p.is_cuda for p in params):
+        try:
+            return torch.optim.Adam(params, lr=lr, fused=True)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.Adam(params, lr=lr)
+
+
 def train_step(net, optimizer, loss_function, images, labels, autocast_dtype=None):
     """The hot loop body of train.py:73-77: zero_grad -> forward -> loss -> backward -> step."""
     optimizer.zero_grad(set_to_none=True)
@@ -57,10 +69,9 @@ def main(argv=None):
         raise RuntimeError("train.py needs an MI355X: the SS2D kernels have no CPU fallback")
     device = torch.device("cuda:0")
     print(f"using {device} device.")
-    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the dense-conv branch (perf only)
     net = build_model(num_classes=args.num_classes, variant=args.variant).to(device)
     loss_function = nn.CrossEntropyLoss()
-    optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
+    optimizer = make_adam(net.parameters(), lr=0.0001)
     gen = torch.Generator(device=device).manual_seed(0)
     best_acc = 0.0
     for epoch in range(args.epochs):
