@@ -183,8 +183,12 @@ int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft,
  *      updated as torch does (unbiased variance, `momentum`), *num_batches_tracked += 1 when not NULL; save_mean /
  *      save_rstd (C) are written for the backward.
  * bwd: dgamma, dbeta (C) are WRITTEN; dx = gamma*rstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)), dy' = dy * [y > 0] when relu.
+ * `input_shift` (C) or NULL: the layer normalises x + input_shift without that add ever being made -- a per-channel
+ *      constant cancels in (x - mean) and only moves the running mean.  It is the bias of the convolution in front of the
+ *      layer (MedMamba.py:518-523): its add and its (identically zero) gradient reduction are skipped.
  * `scratch`: ms_bn_scratch_floats(C) floats of workspace (per-workgroup partial sums; need not be initialised). */
-int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, const float *gamma, const float *beta, float *running_mean,
+int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, const float *input_shift, const float *gamma, const float *beta,
+                        float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int relu, void *y,
                         int y_is_bf16, float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C,
                         void *stream);

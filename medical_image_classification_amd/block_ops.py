@@ -152,7 +152,8 @@ def _nhwc_ok(t):
 
 class _BatchNormReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, out_bf16):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, out_bf16, shift):
+        """shift: bias of the convolution in front (or None) -- see `conv_branch`; its gradient is identically zero."""
         B, C, H, W = x.shape
         npix = B * H * W
         w = weight.detach().float().contiguous()
@@ -160,13 +161,16 @@ class _BatchNormReLU(torch.autograd.Function):
         y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.channels_last)
         save = torch.empty((2, C), device=x.device, dtype=torch.float32)
         with _lib.on_device(x.device):
+            sh = shift.detach().float().contiguous() if shift is not None else None
             _lib.check(_lib.lib().ms_bn_relu_nhwc_fwd(
-                x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr(), running_mean.data_ptr(),
+                x.data_ptr(), int(x.dtype == torch.bfloat16), sh.data_ptr() if sh is not None else None, w.data_ptr(),
+                b.data_ptr(), running_mean.data_ptr(),
                 running_var.data_ptr(), nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), int(relu),
                 y.data_ptr(), int(out_bf16), save[0].data_ptr(), save[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(),
                 npix, C, _stream(x)), "ms_bn_relu_nhwc_fwd")
         ctx.save_for_backward(x, w, b, save)
         ctx.relu, ctx.wdtype, ctx.bdtype = bool(relu), weight.dtype, bias.dtype
+        ctx.shift_like = shift if shift is not None else None
         return y
 
     @staticmethod
@@ -183,20 +187,21 @@ class _BatchNormReLU(torch.autograd.Function):
                 x.data_ptr(), int(x.dtype == torch.bfloat16), dy.data_ptr(), int(dy.dtype == torch.bfloat16), w.data_ptr(),
                 b.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), dx.data_ptr(), dgb[0].data_ptr(),
                 dgb[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(), B * H * W, C, _stream(x)), "ms_bn_relu_nhwc_bwd")
-        return dx.to(x.dtype), dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None, None, None, None, None, None
+        dshift = torch.zeros_like(ctx.shift_like) if ctx.shift_like is not None else None      # d/d(shift) of BN(x + shift) == 0
+        return dx.to(x.dtype), dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None, None, None, None, None, None, dshift
 
 
-def batchnorm_relu(bn, x, relu):
-    """`relu(bn(x))` (or `bn(x)`) for an nn.BatchNorm2d in TRAINING mode on a channels_last CUDA tensor, through
+def batchnorm_relu(bn, x, relu, shift=None):
+    """`relu(bn(x + shift))` (or `bn(x + shift)`; shift = per-channel constant or None) for an nn.BatchNorm2d in TRAINING mode on a channels_last CUDA tensor, through
     ms_bn_relu_nhwc_* (batch statistics, running-statistics update and num_batches_tracked as torch does).  Anything else
     (eval mode, no affine / no running stats, cumulative momentum, other layouts) goes through the module itself."""
     if not (bn.training and x.is_cuda and _nhwc_ok(x) and bn.affine and bn.track_running_stats and bn.momentum is not None
             and type(bn) is torch.nn.BatchNorm2d and bn.running_mean is not None):
-        y = bn(x)
+        y = bn(x if shift is None else x + shift.view(1, -1, 1, 1).to(x.dtype))
         return torch.relu(y) if relu else y
     out_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
     return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                                bn.eps, relu, out_bf16)
+                                bn.eps, relu, out_bf16, shift)
 
 
 def conv_branch(seq, x):
@@ -209,9 +214,22 @@ def conv_branch(seq, x):
     if kinds != [nn.BatchNorm2d, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.ReLU]:
         return seq(x)
     x = batchnorm_relu(mods[0], x, False)
-    x = mods[1](x)
-    x = batchnorm_relu(mods[2], x, True)
-    x = mods[4](x)
-    x = batchnorm_relu(mods[5], x, True)
+    x = _conv_then_bn(mods[1], mods[2], x)
+    x = _conv_then_bn(mods[4], mods[5], x)
     x = mods[7](x)
     return mods[8](x)
+
+
+def _conv_then_bn(conv, bn, x):
+    """relu(bn(conv(x))) for a Conv2d followed by a training-mode BatchNorm2d: the conv's bias is a per-channel constant
+    in front of a mean subtraction, so it is handed to the BatchNorm kernel as `input_shift` (running mean only) instead
+    of being added to the activation and having a full-tensor reduction compute its (exactly zero) gradient."""
+    fused_bn = (bn.training and x.is_cuda and conv.bias is not None and bn.affine and bn.track_running_stats
+                and bn.momentum is not None and type(bn) is torch.nn.BatchNorm2d and type(conv) is torch.nn.Conv2d
+                and conv.padding_mode == "zeros")
+    if not fused_bn:
+        return batchnorm_relu(bn, conv(x), True)
+    y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if not _nhwc_ok(y):
+        return batchnorm_relu(bn, y + conv.bias.view(1, -1, 1, 1).to(y.dtype), True)
+    return batchnorm_relu(bn, y, True, shift=conv.bias)

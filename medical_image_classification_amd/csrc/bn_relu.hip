@@ -53,11 +53,12 @@ __device__ __forceinline__ void bn_block_combine(float a, float b, int ct, int c
 // pass 1 forward: sums of (x - pivot) and (x - pivot)^2 per channel, pivot = running_mean (conditioning)
 template <typename T>
 __global__ void __launch_bounds__(kBnThreads)
-bn_stats_kernel(const T *__restrict__ x, const float *__restrict__ pivot, float *__restrict__ part, int64_t npix, int C,
+bn_stats_kernel(const T *__restrict__ x, const float *__restrict__ pivot, const float *__restrict__ shift,
+                float *__restrict__ part, int64_t npix, int C,
                 int ct, int rpi) {
     const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
     const bool cv = c < C;
-    const float pv = cv ? pivot[c] : 0.0f;
+    const float pv = cv ? pivot[c] - (shift ? shift[c] : 0.0f) : 0.0f;      // pivot for x = pivot for (x + shift) - shift
     float s1 = 0.0f, s2 = 0.0f;
     if (cv) {
         for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
@@ -87,8 +88,8 @@ __device__ __forceinline__ void bn_sum_partials(const float *part, int nblk, int
 
 // finalize forward: batch mean / rstd (saved for apply and backward) and the running-statistics update
 __global__ void __launch_bounds__(kFinCh * kFinSlots)
-bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, float *__restrict__ running_mean,
-                       float *__restrict__ running_var, long long *__restrict__ nbt, float momentum, float eps,
+bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, const float *__restrict__ shift,
+                       float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt, float momentum, float eps,
                        float *__restrict__ save_mean, float *__restrict__ save_rstd, int64_t npix, int C) {
     const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
     const bool cv = c < C;
@@ -98,10 +99,11 @@ bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, float *__restri
         const float inv_n = 1.0f / (float)npix;
         const float m1 = s1 * inv_n;                                  // E[x - pivot], pivot = running_mean
         const float var = fmaxf(s2 * inv_n - m1 * m1, 0.0f);          // biased variance
-        const float mean = running_mean[c] + m1;
+        const float sh = shift ? shift[c] : 0.0f;                      // the layer's logical input is x + shift
+        const float mean = running_mean[c] - sh + m1;                 // batch mean of x
         save_mean[c] = mean; save_rstd[c] = rsqrtf(var + eps);
         const float unb = npix > 1 ? var * ((float)npix / (float)(npix - 1)) : var;
-        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (mean + sh);
         running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unb;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
@@ -182,7 +184,7 @@ static unsigned bn_blocks(int64_t npix, int rpi) {
 
 int bn_scratch_floats(int C) { return 2 * (C > 0 ? C : 0) * kBnMaxBlocks; }
 
-int bn_fwd_dispatch(const void *x, int x_bf16, const float *gamma, const float *beta, float *running_mean,
+int bn_fwd_dispatch(const void *x, int x_bf16, const float *shift, const float *gamma, const float *beta, float *running_mean,
                     float *running_var, long long *nbt, float momentum, float eps, int relu, void *y, int y_bf16,
                     float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C, hipStream_t s) {
     if (!x || !gamma || !beta || !running_mean || !running_var || !y || !save_mean || !save_rstd || !scratch) return MS_ERR_NULL;
@@ -191,9 +193,9 @@ int bn_fwd_dispatch(const void *x, int x_bf16, const float *gamma, const float *
     const unsigned nblk = bn_blocks(npix, g.rows_per_iter);
     const dim3 grid(nblk, (unsigned)g.ncb), block(kBnThreads);
     using bf = unsigned short;
-    if (x_bf16) hipLaunchKernelGGL((bn_stats_kernel<bf>), grid, block, 0, s, (const bf *)x, running_mean, scratch, npix, C, g.ct, g.rows_per_iter);
-    else        hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, 0, s, (const float *)x, running_mean, scratch, npix, C, g.ct, g.rows_per_iter);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, running_mean, running_var, nbt,
+    if (x_bf16) hipLaunchKernelGGL((bn_stats_kernel<bf>), grid, block, 0, s, (const bf *)x, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
+    else        hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, 0, s, (const float *)x, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, shift, running_mean, running_var, nbt,
                        momentum, eps, save_mean, save_rstd, npix, C);
 #define MS_BN_APPLY(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), grid, block, 0, s, (const TI *)x, gamma, beta, save_mean, save_rstd, \
         relu, (TO *)y, npix, C, g.ct, g.rows_per_iter)

@@ -462,6 +462,29 @@ def test_batchnorm_relu_kernels_vs_torch(cfg, relu, bf16):
     assert int(bn.num_batches_tracked) == 1 == int(ref.num_batches_tracked)
 
 
+def test_batchnorm_input_shift_equals_explicit_add():
+    """bn(x + shift) through `input_shift` == the explicit add: output, gradients, running statistics; d/dshift == 0."""
+    from medical_image_classification_amd.block_ops import batchnorm_relu
+    torch.manual_seed(19)
+    C = 48
+    mk = lambda: torch.nn.BatchNorm2d(C).to(dev()).train()
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(4, C, 9, 9, device=dev()).contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(x)
+    sh = (torch.randn(C, device=dev()) * 3).requires_grad_()
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = batchnorm_relu(a, xa, True, shift=sh)
+    yb = batchnorm_relu(b, (xb + sh.detach().view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last), True)
+    ya.backward(g); yb.backward(g)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.running_var, b.running_var, rtol=1e-5, atol=1e-5)
+    assert sh.grad is not None and float(sh.grad.abs().max()) == 0.0
+
+
 def test_conv_branch_fused_bn_matches_sequential():
     """conv_branch(seq, x) == seq(x) for the conv33conv33conv11 Sequential (training mode): output, input gradient,
     parameter gradients and BatchNorm buffers."""
