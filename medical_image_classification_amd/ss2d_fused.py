@@ -290,7 +290,7 @@ def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):
     C = dt_rank + 2 * d_state
     M = B * H * W
     from .ss2d_ops import linear_splitk
-    proj = linear_splitk(xc.view(M, D), x_proj_weight.view(4 * C, D)).float()               # (M, 4C)
+    proj = linear_splitk(xc.view(M, D), x_proj_weight.view(4 * C, D), out_fp32=True)        # (M, 4C) fp32
     return proj.view(B, H * W, 4, C), None, dt_projs_weight
 
 

@@ -127,7 +127,7 @@ class _LinearSplitK(torch.autograd.Function):
     in fp32 -- split-K by construction."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, out_fp32=False):
         ac = torch.is_autocast_enabled()
         dt = torch.get_autocast_dtype("cuda") if ac else None
         xm = x.reshape(-1, x.shape[-1])
@@ -136,7 +136,8 @@ class _LinearSplitK(torch.autograd.Function):
         else:
             w = weight
         with torch.autocast(device_type="cuda", enabled=False):
-            y = torch.mm(xm, w.t())
+            # out_fp32: the consumer wants fp32 (the scan operands): let the GEMM write it instead of casting afterwards
+            y = torch.mm(xm, w.t(), out_dtype=torch.float32) if (out_fp32 and xm.dtype != torch.float32) else torch.mm(xm, w.t())
         ctx.save_for_backward(xm, w)
         ctx.xshape, ctx.wdtype, ctx.xdtype = x.shape, weight.dtype, x.dtype
         return y.view(*x.shape[:-1], weight.shape[0])
@@ -155,15 +156,18 @@ class _LinearSplitK(torch.autograd.Function):
                     S = cand
                     break
             if S > 1:
-                part = torch.bmm(dym.view(S, M // S, N).transpose(1, 2), xm.view(S, M // S, K))    # (S, N, K)
-                dw = part.float().sum(dim=0)
+                a, b = dym.view(S, M // S, N).transpose(1, 2), xm.view(S, M // S, K)
+                part = torch.bmm(a, b, out_dtype=torch.float32) if xm.dtype != torch.float32 else torch.bmm(a, b)   # (S, N, K)
+                dw = part.sum(dim=0)
             else:
                 dw = torch.mm(dym.t(), xm).float()
-        return (dx.view(ctx.xshape).to(ctx.xdtype) if dx is not None else None), dw.to(ctx.wdtype)
+        return (dx.view(ctx.xshape).to(ctx.xdtype) if dx is not None else None), dw.to(ctx.wdtype), None
 
 
-def linear_splitk(x, weight):
-    """F.linear(x, weight) (no bias) with a split-K weight gradient; falls back to F.linear for small row counts."""
+def linear_splitk(x, weight, out_fp32=False):
+    """F.linear(x, weight) (no bias) with a split-K weight gradient; falls back to F.linear for small row counts.
+    out_fp32: return fp32 even when the GEMM runs in bf16 under autocast."""
     if x.is_cuda and x.numel() // x.shape[-1] >= 8192:
-        return _LinearSplitK.apply(x, weight)
-    return torch.nn.functional.linear(x, weight)
+        return _LinearSplitK.apply(x, weight, out_fp32)
+    y = torch.nn.functional.linear(x, weight)
+    return y.float() if out_fp32 else y
