@@ -178,7 +178,9 @@ int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft,
                       int64_t npix, int64_t pixels_per_sample, int C, void *stream);
 
 /* ---- training-mode BatchNorm2d (+ fused ReLU) of the conv branch (MedMamba.py:517-527, 533-535) ------------------
- * x, y, dy, dx : (npix, C), unit channel stride = the memory of an NCHW tensor in channels_last format; bf16 or fp32.
+ * y, dy, dx : (npix, C) contiguous = the memory of an NCHW tensor in channels_last format; bf16 or fp32.
+ * x : npix rows of C channels, unit channel stride, `x_pixel_stride` elements between pixels (C when contiguous; the left
+ *     half of the (.., 2C) block input is normalised in place, without the copy `.contiguous()` would make).
  * fwd: batch statistics (biased variance, fp32), y = [relu]((x - mean) * rstd * gamma + beta), running statistics
  *      updated as torch does (unbiased variance, `momentum`), *num_batches_tracked += 1 when not NULL; save_mean /
  *      save_rstd (C) are written for the backward.
@@ -187,12 +189,12 @@ int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft,
  *      constant cancels in (x - mean) and only moves the running mean.  It is the bias of the convolution in front of the
  *      layer (MedMamba.py:518-523): its add and its (identically zero) gradient reduction are skipped.
  * `scratch`: ms_bn_scratch_floats(C) floats of workspace (per-workgroup partial sums; need not be initialised). */
-int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, const float *input_shift, const float *gamma, const float *beta,
+int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const float *input_shift, const float *gamma, const float *beta,
                         float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int relu, void *y,
                         int y_is_bf16, float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C,
                         void *stream);
-int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
+int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
                         const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
                         float *scratch, int64_t npix, int C, void *stream);
 int ms_bn_scratch_floats(int C);

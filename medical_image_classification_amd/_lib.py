@@ -101,9 +101,9 @@ def lib():
     h.ms_block_tail_bwd.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_i64, c_int, c_vp]
     h.ms_dtproj_fwd.argtypes = [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
     h.ms_dtproj_bwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
-    h.ms_bn_relu_nhwc_fwd.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_int, c_vp, c_int, c_vp, c_vp, c_vp,
+    h.ms_bn_relu_nhwc_fwd.argtypes = [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_int, c_vp, c_int, c_vp, c_vp, c_vp,
                                       c_i64, c_int, c_vp]
-    h.ms_bn_relu_nhwc_bwd.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]
+    h.ms_bn_relu_nhwc_bwd.argtypes = [c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]
     h.ms_bn_scratch_floats.argtypes = [c_int]
     h.ms_status_string.restype = ctypes.c_char_p
     h.ms_status_string.argtypes = [ctypes.c_int]

@@ -146,8 +146,20 @@ def _bn_scratch(device, C):
     return buf
 
 
+def _nhwc_pixel_stride(t):
+    """Pixel stride of an NCHW-shaped tensor whose memory is rows of C channels (unit channel stride, uniform stride
+    between pixels: channels_last, or a channel slice of a wider channels_last tensor); None if it is anything else."""
+    if t.dim() != 4 or t.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    B, C, H, W = t.shape
+    ps = t.stride(3)
+    if t.stride(1) != 1 or ps < C or t.stride(2) != W * ps or (B > 1 and t.stride(0) != H * W * ps):
+        return None
+    return ps
+
+
 def _nhwc_ok(t):
-    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and t.dtype in (torch.float32, torch.bfloat16)
+    return _nhwc_pixel_stride(t) == t.shape[1]
 
 
 class _BatchNormReLU(torch.autograd.Function):
@@ -156,20 +168,22 @@ class _BatchNormReLU(torch.autograd.Function):
         """shift: bias of the convolution in front (or None) -- see `conv_branch`; its gradient is identically zero."""
         B, C, H, W = x.shape
         npix = B * H * W
+        ps = _nhwc_pixel_stride(x)
         w = weight.detach().float().contiguous()
         b = bias.detach().float().contiguous()
-        y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.channels_last)
+        y = torch.empty((B, C, H, W), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32,
+                        memory_format=torch.channels_last)
         save = torch.empty((2, C), device=x.device, dtype=torch.float32)
         with _lib.on_device(x.device):
             sh = shift.detach().float().contiguous() if shift is not None else None
             _lib.check(_lib.lib().ms_bn_relu_nhwc_fwd(
-                x.data_ptr(), int(x.dtype == torch.bfloat16), sh.data_ptr() if sh is not None else None, w.data_ptr(),
+                x.data_ptr(), int(x.dtype == torch.bfloat16), ps, sh.data_ptr() if sh is not None else None, w.data_ptr(),
                 b.data_ptr(), running_mean.data_ptr(),
                 running_var.data_ptr(), nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), int(relu),
                 y.data_ptr(), int(out_bf16), save[0].data_ptr(), save[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(),
                 npix, C, _stream(x)), "ms_bn_relu_nhwc_fwd")
         ctx.save_for_backward(x, w, b, save)
-        ctx.relu, ctx.wdtype, ctx.bdtype = bool(relu), weight.dtype, bias.dtype
+        ctx.relu, ctx.wdtype, ctx.bdtype, ctx.ps = bool(relu), weight.dtype, bias.dtype, ps
         ctx.shift_like = shift if shift is not None else None
         return y
 
@@ -184,7 +198,7 @@ class _BatchNormReLU(torch.autograd.Function):
         dgb = torch.empty((2, C), device=x.device, dtype=torch.float32)
         with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_bn_relu_nhwc_bwd(
-                x.data_ptr(), int(x.dtype == torch.bfloat16), dy.data_ptr(), int(dy.dtype == torch.bfloat16), w.data_ptr(),
+                x.data_ptr(), int(x.dtype == torch.bfloat16), ctx.ps, dy.data_ptr(), int(dy.dtype == torch.bfloat16), w.data_ptr(),
                 b.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), dx.data_ptr(), dgb[0].data_ptr(),
                 dgb[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(), B * H * W, C, _stream(x)), "ms_bn_relu_nhwc_bwd")
         dshift = torch.zeros_like(ctx.shift_like) if ctx.shift_like is not None else None      # d/d(shift) of BN(x + shift) == 0
@@ -195,8 +209,9 @@ def batchnorm_relu(bn, x, relu, shift=None):
     """`relu(bn(x + shift))` (or `bn(x + shift)`; shift = per-channel constant or None) for an nn.BatchNorm2d in TRAINING mode on a channels_last CUDA tensor, through
     ms_bn_relu_nhwc_* (batch statistics, running-statistics update and num_batches_tracked as torch does).  Anything else
     (eval mode, no affine / no running stats, cumulative momentum, other layouts) goes through the module itself."""
-    if not (bn.training and x.is_cuda and _nhwc_ok(x) and bn.affine and bn.track_running_stats and bn.momentum is not None
+    if not (bn.training and x.is_cuda and _nhwc_pixel_stride(x) is not None and bn.affine and bn.track_running_stats and bn.momentum is not None
             and type(bn) is torch.nn.BatchNorm2d and bn.running_mean is not None):
+        x = x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x
         y = bn(x if shift is None else x + shift.view(1, -1, 1, 1).to(x.dtype))
         return torch.relu(y) if relu else y
     out_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
@@ -212,7 +227,7 @@ def conv_branch(seq, x):
     kinds = [type(m) for m in mods]
     nn = torch.nn
     if kinds != [nn.BatchNorm2d, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.ReLU]:
-        return seq(x)
+        return seq(x.contiguous(memory_format=torch.channels_last))
     x = batchnorm_relu(mods[0], x, False)
     x = _conv_then_bn(mods[1], mods[2], x)
     x = _conv_then_bn(mods[4], mods[5], x)

@@ -33,11 +33,11 @@ int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, 
 int dtproj_fwd_dispatch(const float *proj, const float *W, float *delta, int64_t npix, int D, int R, int C, hipStream_t s);
 int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, int64_t npix, int D,
                         int R, int C, hipStream_t s);
-int bn_fwd_dispatch(const void *x, int x_bf16, const float *shift, const float *gamma, const float *beta, float *running_mean,
+int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, const float *gamma, const float *beta, float *running_mean,
                     float *running_var, long long *nbt, float momentum, float eps, int relu, void *y, int y_bf16,
                     float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C, hipStream_t s);
 int bn_scratch_floats(int C);
-int bn_bwd_dispatch(const void *x, int x_bf16, const void *dy, int dy_bf16, const float *gamma, const float *beta,
+int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int dy_bf16, const float *gamma, const float *beta,
                     const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
                     float *scratch, int64_t npix, int C, hipStream_t s);
 }  // namespace ms
@@ -131,20 +131,20 @@ int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, floa
     return ms::dtproj_bwd_dispatch(ddelta, proj, Wdt, dproj, dWdt, npix, D, R, row_width, (hipStream_t)stream);
 }
 
-int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, const float *input_shift, const float *gamma, const float *beta,
+int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const float *input_shift, const float *gamma, const float *beta,
                         float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int relu, void *y,
                         int y_is_bf16, float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C,
                         void *stream) {
-    return ms::bn_fwd_dispatch(x, x_is_bf16, input_shift, gamma, beta, running_mean, running_var, (long long *)num_batches_tracked,
+    return ms::bn_fwd_dispatch(x, x_is_bf16, x_pixel_stride, input_shift, gamma, beta, running_mean, running_var, (long long *)num_batches_tracked,
                                momentum, eps, relu, y, y_is_bf16, save_mean, save_rstd, scratch, npix, C,
                                (hipStream_t)stream);
 }
 
-int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
+int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
                         const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
                         float *scratch, int64_t npix, int C, void *stream) {
-    return ms::bn_bwd_dispatch(x, x_is_bf16, dy, dy_is_bf16, gamma, beta, save_mean, save_rstd, relu, dx, dgamma, dbeta,
+    return ms::bn_bwd_dispatch(x, x_is_bf16, x_pixel_stride, dy, dy_is_bf16, gamma, beta, save_mean, save_rstd, relu, dx, dgamma, dbeta,
                                scratch, npix, C, (hipStream_t)stream);
 }
 

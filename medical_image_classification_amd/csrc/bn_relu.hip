@@ -53,7 +53,7 @@ __device__ __forceinline__ void bn_block_combine(float a, float b, int ct, int c
 // pass 1 forward: sums of (x - pivot) and (x - pivot)^2 per channel, pivot = running_mean (conditioning)
 template <typename T>
 __global__ void __launch_bounds__(kBnThreads)
-bn_stats_kernel(const T *__restrict__ x, const float *__restrict__ pivot, const float *__restrict__ shift,
+bn_stats_kernel(const T *__restrict__ x, int64_t xps, const float *__restrict__ pivot, const float *__restrict__ shift,
                 float *__restrict__ part, int64_t npix, int C,
                 int ct, int rpi) {
     const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
@@ -62,7 +62,7 @@ bn_stats_kernel(const T *__restrict__ x, const float *__restrict__ pivot, const 
     float s1 = 0.0f, s2 = 0.0f;
     if (cv) {
         for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
-            const float v = bn_ld(x + p * C + c) - pv;
+            const float v = bn_ld(x + p * xps + c) - pv;
             s1 += v; s2 = fmaf(v, v, s2);
         }
     }
@@ -122,14 +122,14 @@ bn_finalize_bwd_kernel(const float *__restrict__ part, int nblk, float *__restri
 // pass 2 forward: y = [relu]((x - mean) * rstd * gamma + beta)
 template <typename T, typename TO>
 __global__ void __launch_bounds__(kBnThreads)
-bn_apply_kernel(const T *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+bn_apply_kernel(const T *__restrict__ x, int64_t xps, const float *__restrict__ gamma, const float *__restrict__ beta,
                 const float *__restrict__ save_mean, const float *__restrict__ save_rstd, int relu, TO *__restrict__ y,
                 int64_t npix, int C, int ct, int rpi) {
     const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
     if (c >= C) return;
     const float g = gamma[c] * save_rstd[c], b = beta[c] - save_mean[c] * g;
     for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
-        float v = fmaf(bn_ld(x + p * C + c), g, b);
+        float v = fmaf(bn_ld(x + p * xps + c), g, b);
         if (relu) v = fmaxf(v, 0.0f);
         bn_st(y + p * C + c, v);
     }
@@ -138,7 +138,7 @@ bn_apply_kernel(const T *__restrict__ x, const float *__restrict__ gamma, const 
 // pass 1 backward: dbeta = sum dy', dgamma = sum dy' * xhat, dy' = dy * [y > 0]
 template <typename T, typename TG>
 __global__ void __launch_bounds__(kBnThreads)
-bn_bwd_reduce_kernel(const T *__restrict__ x, const TG *__restrict__ dy, const float *__restrict__ gamma,
+bn_bwd_reduce_kernel(const T *__restrict__ x, int64_t xps, const TG *__restrict__ dy, const float *__restrict__ gamma,
                      const float *__restrict__ beta, const float *__restrict__ save_mean,
                      const float *__restrict__ save_rstd, int relu, float *__restrict__ part, int64_t npix, int C, int ct,
                      int rpi) {
@@ -148,7 +148,7 @@ bn_bwd_reduce_kernel(const T *__restrict__ x, const TG *__restrict__ dy, const f
     if (cv) {
         const float mean = save_mean[c], rstd = save_rstd[c], g = gamma[c], b = beta[c];
         for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
-            const float xh = (bn_ld(x + p * C + c) - mean) * rstd;
+            const float xh = (bn_ld(x + p * xps + c) - mean) * rstd;
             float d = bn_ld(dy + p * C + c);
             if (relu && fmaf(xh, g, b) <= 0.0f) d = 0.0f;
             sg = fmaf(d, xh, sg); sb += d;
@@ -160,7 +160,7 @@ bn_bwd_reduce_kernel(const T *__restrict__ x, const TG *__restrict__ dy, const f
 // pass 2 backward: dx = gamma * rstd * (dy' - dbeta/n - xhat * dgamma/n)
 template <typename T, typename TG>
 __global__ void __launch_bounds__(kBnThreads)
-bn_bwd_apply_kernel(const T *__restrict__ x, const TG *__restrict__ dy, const float *__restrict__ gamma,
+bn_bwd_apply_kernel(const T *__restrict__ x, int64_t xps, const TG *__restrict__ dy, const float *__restrict__ gamma,
                     const float *__restrict__ beta, const float *__restrict__ save_mean,
                     const float *__restrict__ save_rstd, int relu, const float *__restrict__ dgamma,
                     const float *__restrict__ dbeta, TG *__restrict__ dx, int64_t npix, int C, int ct, int rpi) {
@@ -170,7 +170,7 @@ bn_bwd_apply_kernel(const T *__restrict__ x, const TG *__restrict__ dy, const fl
     const float mean = save_mean[c], rstd = save_rstd[c], g = gamma[c], b = beta[c];
     const float k1 = dbeta[c] * inv_n, k2 = dgamma[c] * inv_n, gs = g * rstd;
     for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
-        const float xh = (bn_ld(x + p * C + c) - mean) * rstd;
+        const float xh = (bn_ld(x + p * xps + c) - mean) * rstd;
         float d = bn_ld(dy + p * C + c);
         if (relu && fmaf(xh, g, b) <= 0.0f) d = 0.0f;
         bn_st(dx + p * C + c, gs * (d - k1 - xh * k2));
@@ -184,20 +184,21 @@ static unsigned bn_blocks(int64_t npix, int rpi) {
 
 int bn_scratch_floats(int C) { return 2 * (C > 0 ? C : 0) * kBnMaxBlocks; }
 
-int bn_fwd_dispatch(const void *x, int x_bf16, const float *shift, const float *gamma, const float *beta, float *running_mean,
+int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, const float *gamma, const float *beta, float *running_mean,
                     float *running_var, long long *nbt, float momentum, float eps, int relu, void *y, int y_bf16,
                     float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C, hipStream_t s) {
     if (!x || !gamma || !beta || !running_mean || !running_var || !y || !save_mean || !save_rstd || !scratch) return MS_ERR_NULL;
     if (npix <= 0 || C <= 0) return npix == 0 && C > 0 ? MS_OK : MS_ERR_SHAPE;
+    if (xps < C) return MS_ERR_STRIDE;
     const BnGeom g = bn_geom(C);
     const unsigned nblk = bn_blocks(npix, g.rows_per_iter);
     const dim3 grid(nblk, (unsigned)g.ncb), block(kBnThreads);
     using bf = unsigned short;
-    if (x_bf16) hipLaunchKernelGGL((bn_stats_kernel<bf>), grid, block, 0, s, (const bf *)x, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
-    else        hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, 0, s, (const float *)x, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
+    if (x_bf16) hipLaunchKernelGGL((bn_stats_kernel<bf>), grid, block, 0, s, (const bf *)x, xps, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
+    else        hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, 0, s, (const float *)x, xps, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, shift, running_mean, running_var, nbt,
                        momentum, eps, save_mean, save_rstd, npix, C);
-#define MS_BN_APPLY(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), grid, block, 0, s, (const TI *)x, gamma, beta, save_mean, save_rstd, \
+#define MS_BN_APPLY(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), grid, block, 0, s, (const TI *)x, xps, gamma, beta, save_mean, save_rstd, \
         relu, (TO *)y, npix, C, g.ct, g.rows_per_iter)
     if (x_bf16 && y_bf16) MS_BN_APPLY(bf, bf); else if (x_bf16) MS_BN_APPLY(bf, float);
     else if (y_bf16) MS_BN_APPLY(float, bf); else MS_BN_APPLY(float, float);
@@ -205,7 +206,7 @@ int bn_fwd_dispatch(const void *x, int x_bf16, const float *shift, const float *
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
-int bn_bwd_dispatch(const void *x, int x_bf16, const void *dy, int dy_bf16, const float *gamma, const float *beta,
+int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int dy_bf16, const float *gamma, const float *beta,
                     const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
                     float *scratch, int64_t npix, int C, hipStream_t s) {
     if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !scratch) return MS_ERR_NULL;
@@ -215,10 +216,10 @@ int bn_bwd_dispatch(const void *x, int x_bf16, const void *dy, int dy_bf16, cons
     const dim3 grid(nblk, (unsigned)g.ncb), block(kBnThreads);
     using bf = unsigned short;
 #define MS_BN_BWD(TI, TG)                                                                                                          \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TG>), grid, block, 0, s, (const TI *)x, (const TG *)dy, gamma, beta, save_mean,      \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TG>), grid, block, 0, s, (const TI *)x, xps, (const TG *)dy, gamma, beta, save_mean,      \
                        save_rstd, relu, scratch, npix, C, g.ct, g.rows_per_iter);                                                   \
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, dgamma, dbeta, C);            \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TG>), grid, block, 0, s, (const TI *)x, (const TG *)dy, gamma, beta, save_mean,       \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TG>), grid, block, 0, s, (const TI *)x, xps, (const TG *)dy, gamma, beta, save_mean,       \
                        save_rstd, relu, dgamma, dbeta, (TG *)dx, npix, C, g.ct, g.rows_per_iter)
     if (x_bf16 && dy_bf16) { MS_BN_BWD(bf, bf); } else if (x_bf16) { MS_BN_BWD(bf, float); }
     else if (dy_bf16) { MS_BN_BWD(float, bf); } else { MS_BN_BWD(float, float); }

@@ -65,7 +65,8 @@ def fused_block_forward(blk, input):
     the right half -> self_attention, conv branch on the left half (optionally on a side stream: the branches are
     independent until the tail), one-pass concat / shuffle / DropPath / residual tail."""
     left, right = split_halves(input)
-    to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    # NCHW view of the strided left half: the branch's first BatchNorm reads it in place (block_ops.batchnorm_relu)
+    to_nchw = lambda t: t.permute(0, 3, 1, 2)
     if BRANCH_STREAMS:
         cur = torch.cuda.current_stream(input.device)
         side = _side_stream(input.device)

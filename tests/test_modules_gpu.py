@@ -462,6 +462,27 @@ def test_batchnorm_relu_kernels_vs_torch(cfg, relu, bf16):
     assert int(bn.num_batches_tracked) == 1 == int(ref.num_batches_tracked)
 
 
+def test_batchnorm_reads_a_strided_half_in_place():
+    """The first BatchNorm of the conv branch takes the left half of the (B,H,W,2C) block input as a strided NCHW view."""
+    from medical_image_classification_amd.block_ops import batchnorm_relu
+    torch.manual_seed(29)
+    C = 48
+    a = torch.nn.BatchNorm2d(C).to(dev()).train(); b = torch.nn.BatchNorm2d(C).to(dev()).train()
+    b.load_state_dict(a.state_dict())
+    full = torch.randn(3, 10, 7, 2 * C, device=dev())
+    g = torch.randn(3, C, 10, 7, device=dev()).contiguous(memory_format=torch.channels_last)
+    fa, fb = full.clone().requires_grad_(), full.clone().requires_grad_()
+    va = fa[..., :C].permute(0, 3, 1, 2)
+    assert not va.is_contiguous(memory_format=torch.channels_last)
+    ya = batchnorm_relu(a, va, False)
+    yb = b(fb[..., :C].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+    ya.backward(g); yb.backward(g)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(fa.grad, fb.grad, rtol=1e-3, atol=1e-5)
+    assert torch.equal(fa.grad[..., C:], torch.zeros_like(fa.grad[..., C:]))
+    assert torch.allclose(a.running_var, b.running_var, rtol=1e-5, atol=1e-6)
+
+
 def test_batchnorm_input_shift_equals_explicit_add():
     """bn(x + shift) through `input_shift` == the explicit add: output, gradients, running statistics; d/dshift == 0."""
     from medical_image_classification_amd.block_ops import batchnorm_relu
