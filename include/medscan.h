@@ -71,6 +71,14 @@ typedef enum MsStatus {
 #define MS_SCAN_A_IS_LOG 2   /* `A` holds A_log; the kernels use A = -exp(A_log) (what SS2D computes before every call,
                                 MedMamba.py:407) and the backward accumulates the gradient w.r.t. A_log in dA */
 
+#define MS_SCAN_ACCUMULATE 4 /* forward: out += result; backward: du += , ddelta += (same thread reads and writes each element:
+                                launches over disjoint state slices of one scan can add up in place) */
+#define MS_SCAN_BC_MAP(dir) (((dir) + 1) << 4)
+                             /* SS2D mode only: the B/C rows (and dB/dC) are addressed through the pixel order of direction
+                                `dir` (0..3) for EVERY group, while u/delta/out keep their own group's order -- the SSD layout
+                                of CNN_Mamba.py:506-519, where the four directions' B/C form one concatenated state vector.
+                                Requires the scalar-decay form (A_dstate_stride == 0). */
+
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;
     int32_t delta_softplus;                 /* flags: MS_SCAN_SOFTPLUS | MS_SCAN_A_IS_LOG (historically a bool: 1 = softplus) */

@@ -18,6 +18,7 @@ is split into slices of <= 16 states whose outputs add (the recurrence is indepe
 `selective_scan_fn` call per slice.  No CPU fallback.
 """
 import math
+import os
 from functools import partial
 from typing import Callable
 
@@ -33,6 +34,7 @@ from .medmamba import CONV_CHANNELS_LAST, DropPath, PatchEmbed2D, PatchMerging2D
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc
 
+SSD_PIXEL_ORDER = os.environ.get("MEDSCAN_SSD_PIXEL", "1") == "1"     # ssd_scan_merge: pixel-order kernels vs gathered copies
 _STATE_SLICE = 16      # states per kernel call (the backward kernels are built for dstate <= 16)
 
 
@@ -138,7 +140,12 @@ def ssd_scan_merge(mod, xc):
     B, H, W, conv_dim = xc.shape
     L, K = H * W, 4
     GN = mod.ngroups * mod.d_state
-    # 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
+    if SSD_PIXEL_ORDER and mod.ngroups == 1 and mod.d_state <= 16 and H * W < (1 << 22):
+        # native path: the scan kernels take the four pixel orders themselves, one launch per direction's B/C slice
+        from .ss2d_fused import ssd_scan_merge_pixel
+        return ssd_scan_merge_pixel(xc, -torch.exp(mod.A_logs.float()), mod.Ds, mod.dt_bias.view(-1), mod.d_ssm, mod.d_state,
+                                    mod.nheads, mod.headdim, mod.D_has_hdim)
+    # general path (ngroups > 1 or d_state > 16): 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
     idx, inv = _scan_orders(H, W, xc.device)
     xs4 = xc.reshape(B, L, conv_dim)[:, idx.reshape(-1)].view(B, K, L, conv_dim).transpose(1, 2)
     xs, Bs, Cs, dts = torch.split(xs4, [mod.d_ssm, GN, GN, mod.nheads], dim=-1)

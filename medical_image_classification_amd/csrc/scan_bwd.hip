@@ -25,7 +25,8 @@ namespace ms {
 constexpr int kWPB = 4;      // waves per workgroup in the backward: independent except for the per-chunk dB/dC combine
 
 // SA: scalar decay per channel (A_dstate_stride == 0, the SSD form): one exp2 and one stored decay per position.
-template <int NPL, int CW, int MODE, bool SA = false>
+// BCM: the B/C rows and the dB/dC flush follow the pixel order of one fixed direction (MS_SCAN_BC_MAP, see scan_fwd.hip).
+template <int NPL, int CW, int MODE, bool SA = false, bool BCM = false>
 __global__ void __launch_bounds__(64 * kWPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4;
@@ -46,6 +47,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     __shared__ __attribute__((aligned(16))) float sTC_[kWPB][kRows * kTP];
     __shared__ float sbias_[kWPB][kCW];
     __shared__ int spos_[kWPB][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
+    __shared__ int sposb_[BCM ? kWPB : 1][2][kCL];   // BCM: the same for the B/C rows' direction
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *sdB = sdB_[wv], *sdC = sdC_[wv];
@@ -105,6 +107,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     pm.H = __builtin_amdgcn_readfirstlane(p.map_h); pm.W = __builtin_amdgcn_readfirstlane(p.map_w);
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     pm.tab = nullptr; pm.tab_base = 0;
+    PosMap pmb = pm;                         // B/C rows (and dB/dC): same order as the activations unless BCM
+    if (BCM) pmb.mode = ((p.delta_softplus >> 4) & 7) - 1;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     float *dBb = q.dB + b * q.dB_batch_stride + g * q.dB_group_stride;
@@ -144,7 +148,11 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     }
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
+        if (MODE == kModeSS2D) {
+            pm.fill_table(spos[ch & 1], l0, lane);
+            if (BCM) pmb.fill_table(sposb_[wv][ch & 1], l0, lane); else pmb = pm;
+            wave_sync();
+        }
         // the state load goes out with (and is waited for with) the tile loads: a load consumed inside the sweeps would
         // put an s_waitcnt vmcnt(0) there and expose the whole prefetch
 #pragma unroll
@@ -152,8 +160,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         tile.fetch(ru, ub, u_sd, u_sl, l0, pm, nvalid, len);
         tile.fetch(rd, db, dl_sd, dl_sl, l0, pm, nvalid, len);
         tile.fetch(rg, gb, g_sd, g_sl, l0, pm, nvalid, len);
-        rows.fetch(rB, Bb, B_sn, B_sl, l0, pm, N, len);
-        rows.fetch(rC, Cb, C_sn, C_sl, l0, pm, N, len);
+        rows.fetch(rB, Bb, B_sn, B_sl, l0, pmb, N, len);
+        rows.fetch(rC, Cb, C_sn, C_sl, l0, pmb, N, len);
     };
     fetch(n_chunks - 1);
     wave_sync();                                           // sbias visible
@@ -276,9 +284,17 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             }
         }
         wave_sync();
-        if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
-        tile.store(su, dub, du_sd, du_sl, l0, pm, nvalid, len);
-        tile.store_ddelta(sg_, sdl, sp_mask, ddb, dd_sd, dd_sl, l0, pm, nvalid, len, dbk);
+        if (MODE == kModeSS2D) {                                                 // the prefetch moved the maps to the next chunk
+            pm.tab = spos[ch & 1]; pm.tab_base = l0;
+            if (BCM) { pmb.tab = sposb_[wv][ch & 1]; pmb.tab_base = l0; } else pmb = pm;
+        }
+        if (p.delta_softplus & MS_SCAN_ACCUMULATE) {
+            tile.template store<true>(su, dub, du_sd, du_sl, l0, pm, nvalid, len);
+            tile.template store_ddelta<true>(sg_, sdl, sp_mask, ddb, dd_sd, dd_sl, l0, pm, nvalid, len, dbk);
+        } else {
+            tile.store(su, dub, du_sd, du_sl, l0, pm, nvalid, len);
+            tile.store_ddelta(sg_, sdl, sp_mask, ddb, dd_sd, dd_sl, l0, pm, nvalid, len, dbk);
+        }
         // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
         // combine the dB / dC tiles of the workgroup's waves (same batch and group, adjacent channel blocks) and add the
         // sums to global memory: kWPB x fewer atomics than one flush per wave.  The only two barriers of the chunk.
@@ -297,7 +313,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     for (int w = 0; w < kWPB; ++w) v += (tc ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
                     if (n < N && l < len) {
                         float *base = tc ? dCb : dBb;
-                        atomicAdd(base + __mul24(pm.tab[l], tc ? dC_sl : dB_sl) + n, v);
+                        atomicAdd(base + __mul24(pmb.tab[l], tc ? dC_sl : dB_sl) + n, v);
                     }
                     continue;
                 }
@@ -368,8 +384,13 @@ static int launch_bwd(const MsScanBwdParams &q, int n_chunks, hipStream_t stream
                        fits24(q.dB_l_stride) && fits24(q.dC_l_stride);
     if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
     const bool sa = p.A_dstate_stride == 0 && p.dstate > 1;
+    const int bc_dir = ((p.delta_softplus >> 4) & 7) - 1;       // MS_SCAN_BC_MAP
+    if (bc_dir >= 0 && (p.map_h <= 0 || !sa || bc_dir > 3)) return MS_ERR_SHAPE;
     switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
-        case kModeSS2D: hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb); break;
+        case kModeSS2D:
+            if (bc_dir >= 0) hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D, true, true>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb);
+            else hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb);
+            break;
         case kModeCL:
             if (sa) hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL, true>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb);
             else    hipLaunchKernelGGL((scan_bwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWPB), 0, stream, q, n_chunks, ncb);

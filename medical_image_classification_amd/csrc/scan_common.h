@@ -158,6 +158,7 @@ struct TileIO {
     static __device__ __forceinline__ int ak(int k) { return LCONTIG ? k : 0; }
     // backward: ddelta = d delta' * softplus'(delta + bias), the derivative recovered from the staged delta' tile
     // (sp_mask = 0: no softplus, factor 1); acc collects the stored values (ddelta_bias partial sums of this lane)
+    template <bool ACC = false>
     __device__ __forceinline__ void store_ddelta(const float *s, const float *sdl, unsigned sp_mask, float *base, int sd, int sl,
                                                  int lbase, const PosMap &pm, int nvalid, int len, float (&acc)[NA]) const {
         char *b = reinterpret_cast<char *>(base);
@@ -165,15 +166,23 @@ struct TileIO {
         for (int k = 0; k < NE; ++k) {
             const float f = bits_f((f_bits(sigmoid_from_softplus(sdl[soff(k)])) & sp_mask) | (f_bits(1.0f) & ~sp_mask));
             const float v = s[soff(k)] * f;
-            if (ok(k, nvalid, len)) { *reinterpret_cast<float *>(b + goff(k, sd, sl, lbase, pm)) = v; acc[ak(k)] += v; }
+            if (ok(k, nvalid, len)) {
+                float *o = reinterpret_cast<float *>(b + goff(k, sd, sl, lbase, pm));
+                *o = ACC ? *o + v : v; acc[ak(k)] += v;
+            }
         }
     }
+    // ACC: add to what is there (MS_SCAN_ACCUMULATE); each element is read and written by this thread only
+    template <bool ACC = false>
     __device__ __forceinline__ void store(const float *s, float *base, int sd, int sl, int lbase,
                                           const PosMap &pm, int nvalid, int len) const {
         char *b = reinterpret_cast<char *>(base);
 #pragma unroll
         for (int k = 0; k < NE; ++k)
-            if (ok(k, nvalid, len)) *reinterpret_cast<float *>(b + goff(k, sd, sl, lbase, pm)) = s[soff(k)];
+            if (ok(k, nvalid, len)) {
+                float *o = reinterpret_cast<float *>(b + goff(k, sd, sl, lbase, pm));
+                *o = ACC ? *o + s[soff(k)] : s[soff(k)];
+            }
     }
 };
 

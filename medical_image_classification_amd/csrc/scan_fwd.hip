@@ -24,7 +24,9 @@ template <int CW> constexpr int fwd_waves() { return 32 / CW; }
 
 // SA ("scalar A"): every state of a channel shares one decay rate (A passed with A_dstate_stride == 0 -- the SSD /
 // Mamba-2 form, CNN_Mamba.py:514): a = exp2(delta' * A) is evaluated once per position instead of once per state.
-template <int NPL, int CW, int MODE, bool SA = false>
+// BCM ("B/C map", SS2D mode with MS_SCAN_BC_MAP): the B/C rows follow the pixel order of ONE fixed direction for every
+// group, the activations their own group's -- a second per-chunk position table.
+template <int NPL, int CW, int MODE, bool SA = false, bool BCM = false>
 __global__ void __launch_bounds__(64 * fwd_waves<CW>())
 scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, kWF = fwd_waves<CW>();
@@ -37,6 +39,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     __shared__ float sdl_[kWF][kTile];      // delta' tile
     __shared__ float sbias_[kWF][kCW];
     __shared__ int spos_[kWF][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
+    __shared__ int sposb_[BCM ? kWF : 1][2][kCL];   // BCM: the same for the B/C rows' direction
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *su = su_[wv], *sdl = sdl_[wv], *sbias = sbias_[wv];
@@ -89,6 +92,8 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     pm.H = __builtin_amdgcn_readfirstlane(p.map_h); pm.W = __builtin_amdgcn_readfirstlane(p.map_w);
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     pm.tab = nullptr; pm.tab_base = 0;
+    PosMap pmb = pm;                         // B/C rows: same order as the activations unless BCM
+    if (BCM) pmb.mode = ((p.delta_softplus >> 4) & 7) - 1;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = (p.delta_softplus & MS_SCAN_SOFTPLUS) != 0;
@@ -105,11 +110,15 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     float ru[Tile::NE], rd[Tile::NE], rB[Rows::NE], rC[Rows::NE];
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
-        if (MODE == kModeSS2D) { pm.fill_table(spos[ch & 1], l0, lane); wave_sync(); }
+        if (MODE == kModeSS2D) {
+            pm.fill_table(spos[ch & 1], l0, lane);
+            if (BCM) pmb.fill_table(sposb_[wv][ch & 1], l0, lane); else pmb = pm;
+            wave_sync();
+        }
         tile.fetch(ru, ub, u_sd, u_sl, l0, pm, nvalid, len);
         tile.fetch(rd, db, dl_sd, dl_sl, l0, pm, nvalid, len);
-        rows.fetch(rB, Bb, B_sn, B_sl, l0, pm, N, len);
-        rows.fetch(rC, Cb, C_sn, C_sl, l0, pm, N, len);
+        rows.fetch(rB, Bb, B_sn, B_sl, l0, pmb, N, len);
+        rows.fetch(rC, Cb, C_sn, C_sl, l0, pmb, N, len);
     };
     fetch(0);
     wave_sync();                                           // sbias visible
@@ -160,7 +169,8 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
         }
         wave_sync();
         if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
-        tile.store(su, ob, o_sd, o_sl, l0, pm, nvalid, len);
+        if (p.delta_softplus & MS_SCAN_ACCUMULATE) tile.template store<true>(su, ob, o_sd, o_sl, l0, pm, nvalid, len);
+        else tile.store(su, ob, o_sd, o_sl, l0, pm, nvalid, len);
         wave_sync();
     }
 }
@@ -201,8 +211,13 @@ static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
                        fits24(p.B_l_stride) && fits24(p.C_l_stride);
     if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
     const bool sa = p.A_dstate_stride == 0 && p.dstate > 1;     // scalar decay per channel (SSD form): channel-last variant only
+    const int bc_dir = ((p.delta_softplus >> 4) & 7) - 1;       // MS_SCAN_BC_MAP
+    if (bc_dir >= 0 && (p.map_h <= 0 || !sa || bc_dir > 3)) return MS_ERR_SHAPE;
     switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
-        case kModeSS2D: hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb); break;
+        case kModeSS2D:
+            if (bc_dir >= 0) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D, true, true>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
+            else hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
+            break;
         case kModeCL:
             if (sa) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL, true>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
             else    hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeCL>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);

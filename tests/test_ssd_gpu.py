@@ -153,3 +153,31 @@ def test_crossmamba_vs_restatement(cfg):
             assert p.grad is None, k
         else:
             close(p.grad, pr[k].grad, 2e-3, k)
+
+
+@pytest.mark.parametrize("cfg", [(64, 16, 64, 9, 7, False), (32, 8, 16, 5, 12, True)])
+def test_ssd_pixel_order_kernels_match_gathered_path(cfg, monkeypatch):
+    """ssd_scan_merge through the pixel-order kernels (MS_SCAN_BC_MAP / MS_SCAN_ACCUMULATE, four launches on the conv
+    output itself) == the gathered-copies path (cross-scan materialised, plain operator): output and every gradient."""
+    from medical_image_classification_amd import cnn_mamba as cm
+    d_model, d_state, headdim, H, W, hdim_D = cfg
+    torch.manual_seed(8)
+    m = cm.SS2D_with_SSD(d_model=d_model, d_state=d_state, headdim=headdim, D_has_hdim=hdim_D).to(dev())
+    with torch.no_grad():
+        m.Ds.add_(torch.randn_like(m.Ds) * 0.3); m.A_logs.add_(torch.randn_like(m.A_logs) * 0.3)
+        m.dt_bias.add_(torch.randn_like(m.dt_bias))
+    u = torch.randn(2, H, W, d_model, device=dev())
+    g = torch.randn(2, H, W, d_model, device=dev())
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(cm, "SSD_PIXEL_ORDER", flag)
+        m.zero_grad(set_to_none=True)
+        ui = u.clone().requires_grad_()
+        y = m(ui)
+        y.backward(g)
+        res[flag] = (y.detach(), ui.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    (y1, du1, p1), (y0, du0, p0) = res[True], res[False]
+    close(y1, y0, 1e-4, "y")
+    close(du1, du0, 1e-3, "du")
+    for k in p0:
+        close(p1[k], p0[k], 1e-3, k)
