@@ -30,7 +30,10 @@ template <int NPL, int CW, int MODE, bool SA = false, bool BCM = false>
 __global__ void __launch_bounds__(64 * kWPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, NB = kCL / 4;
-    constexpr int kRows = 4 * NPL * SG, kTP = CW + 4;      // transpose tile: rows x (CW + pad) floats, 16-byte aligned rows
+    // transpose tile: rows of CW floats.  Writes: (r*SG + sg)*CW + c = r*64 + lane, one bank per lane.  Reads: lane rr sums
+    // row rr with CW/4 ds_read_b128 taken in a rotated order, so that the 16 lanes of a pass touch 16 different bank quads
+    // (the sum does not care about the order); a padded pitch of CW + 4 cost a 2-way conflict on every write.
+    constexpr int kRows = 4 * NPL * SG, kTP = CW, kQ = CW / 4;
     static_assert(kRows <= 64, "one lane per (position, state) of a batch");
     using Tile = TileIO<MODE, CW>;
     using Rows = RowIO<MODE, NP, kWPB>;
@@ -38,8 +41,10 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     const MsScanParams &p = q.f;
     __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];          // B / C rows of the chunk: one copy per workgroup
     __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
-    __shared__ __attribute__((aligned(16))) float sdB_[kWPB][NP * kRowPitch];   // this chunk's dB / dC of each wave's channels
-    __shared__ __attribute__((aligned(16))) float sdC_[kWPB][NP * kRowPitch];
+    // this chunk's dB | dC of each wave's channels; the dC tile sits 2 banks past a multiple of 64 from the dB tile, so the
+    // workgroup combine (which reads dB[n][l] and dC[n][l] in one instruction) finds them in different banks
+    constexpr int kDC = NP * kRowPitch + 2;
+    __shared__ float sdBC_[kWPB][kDC + NP * kRowPitch];
     __shared__ float su_[kWPB][kTile];       // u tile      -> du tile
     __shared__ float sdl_[kWPB][kTile];      // delta' tile
     __shared__ float sg__[kWPB][kTile];      // dout tile   -> ddelta tile
@@ -50,7 +55,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     __shared__ int sposb_[BCM ? kWPB : 1][2][kCL];   // BCM: the same for the B/C rows' direction
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *sdB = sdB_[wv], *sdC = sdC_[wv];
+    float *sdB = sdBC_[wv], *sdC = sdBC_[wv] + kDC;
     float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sTB = sTB_[wv], *sTC = sTC_[wv], *sbias = sbias_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
@@ -273,9 +278,10 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             if (kRows == 64 || lane < kRows) {
                 float tb = 0.0f, tc = 0.0f;
 #pragma unroll
-                for (int k4 = 0; k4 < CW / 4; ++k4) {
-                    const float4 x = *reinterpret_cast<const float4 *>(sTB + lane * kTP + 4 * k4);
-                    const float4 y = *reinterpret_cast<const float4 *>(sTC + lane * kTP + 4 * k4);
+                for (int k4 = 0; k4 < kQ; ++k4) {
+                    const int q4 = 4 * ((k4 + lane / (16 / kQ)) % kQ);
+                    const float4 x = *reinterpret_cast<const float4 *>(sTB + lane * kTP + q4);
+                    const float4 y = *reinterpret_cast<const float4 *>(sTC + lane * kTP + q4);
                     tb += (x.x + x.y) + (x.z + x.w);
                     tc += (y.x + y.y) + (y.z + y.w);
                 }
@@ -310,7 +316,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     const int tc = t >= NP;
                     float v = 0.0f;
 #pragma unroll
-                    for (int w = 0; w < kWPB; ++w) v += (tc ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
+                    for (int w = 0; w < kWPB; ++w) v += sdBC_[w][(tc ? kDC : 0) + n * kRowPitch + l];
                     if (n < N && l < len) {
                         float *base = tc ? dCb : dBb;
                         atomicAdd(base + __mul24(pmb.tab[l], tc ? dC_sl : dB_sl) + n, v);
@@ -320,7 +326,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 l = rem % kCL; n = rem / kCL;
                 float v = 0.0f;
 #pragma unroll
-                for (int w = 0; w < kWPB; ++w) v += (isC ? sdC_[w] : sdB_[w])[n * kRowPitch + l];
+                for (int w = 0; w < kWPB; ++w) v += sdBC_[w][(isC ? kDC : 0) + n * kRowPitch + l];
                 if (n < N && l < len) {
                     float *base = isC ? dCb : dBb;
                     atomicAdd(base + (int64_t)(l0 + l) * (isC ? dC_sl : dB_sl) + n * (isC ? dC_sn : dB_sn), v);

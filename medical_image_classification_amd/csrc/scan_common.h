@@ -101,7 +101,10 @@ constexpr int kModeSS2D = 2;     // channel-last activations indexed by pixel th
 template <int MODE, int CW>
 struct TileIO {
     static constexpr bool LCONTIG = MODE == kModeBDL;
-    static constexpr int kPitch = CW + 1;                        // LDS tile pitch (floats)
+    // LDS tile pitch (floats).  Channel-last tiles: lane -> (l = lane / CW, c = lane % CW) lands on address `lane`:
+    // conflict-free at pitch CW (pitch CW + 1 wrapped 64..70 onto banks 0..6: a 2-way conflict on every put / store).
+    // (B,D,L) tiles: lane -> position lane % 32 of two channels: needs an odd pitch.
+    static constexpr int kPitch = LCONTIG ? CW + 1 : CW;
     static constexpr int kTile = kCL * kPitch;
     static constexpr int NE = kCL * CW / 64;                     // elements per lane
     static constexpr int STEP = LCONTIG ? 64 / kCL : 64 / CW;    // channels (LCONTIG) or positions per k
