@@ -44,7 +44,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     // this chunk's dB | dC of each wave's channels; the dC tile sits 2 banks past a multiple of 64 from the dB tile, so the
     // workgroup combine (which reads dB[n][l] and dC[n][l] in one instruction) finds them in different banks
     constexpr int kDC = NP * kRowPitch + 2;
-    __shared__ float sdBC_[kWPB][kDC + NP * kRowPitch];
+    __shared__ float sdBC_[2][kWPB][kDC + NP * kRowPitch];      // double-buffered by chunk parity (see the combine below)
     __shared__ float su_[kWPB][kTile];       // u tile      -> du tile
     __shared__ float sdl_[kWPB][kTile];      // delta' tile
     __shared__ float sg__[kWPB][kTile];      // dout tile   -> ddelta tile
@@ -55,7 +55,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     __shared__ int sposb_[BCM ? kWPB : 1][2][kCL];   // BCM: the same for the B/C rows' direction
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *sdB = sdBC_[wv], *sdC = sdBC_[wv] + kDC;
+
     float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sTB = sTB_[wv], *sTC = sTC_[wv], *sbias = sbias_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
@@ -173,6 +173,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
+        float *sdB = sdBC_[ch & 1][wv], *sdC = sdBC_[ch & 1][wv] + kDC;
         tile.put(su, ru, nvalid, len);
         tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
         tile.put(sg_, rg, nvalid, len);
@@ -303,7 +304,9 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         }
         // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
         // combine the dB / dC tiles of the workgroup's waves (same batch and group, adjacent channel blocks) and add the
-        // sums to global memory: kWPB x fewer atomics than one flush per wave.  The only two barriers of the chunk.
+        // sums to global memory: kWPB x fewer atomics than one flush per wave.  One barrier: the tiles are double-buffered
+        // by chunk parity, so the next chunk's sweeps write the other buffer while slower waves still read this one, and
+        // this buffer is written again only after everyone has passed the NEXT chunk's barrier, i.e. finished this combine.
         __syncthreads();
         {
             constexpr int NT = 64 * kWPB, TOT = 2 * NP * kCL;
@@ -316,7 +319,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     const int tc = t >= NP;
                     float v = 0.0f;
 #pragma unroll
-                    for (int w = 0; w < kWPB; ++w) v += sdBC_[w][(tc ? kDC : 0) + n * kRowPitch + l];
+                    for (int w = 0; w < kWPB; ++w) v += sdBC_[ch & 1][w][(tc ? kDC : 0) + n * kRowPitch + l];
                     if (n < N && l < len) {
                         float *base = tc ? dCb : dBb;
                         atomicAdd(base + __mul24(pmb.tab[l], tc ? dC_sl : dB_sl) + n, v);
@@ -326,14 +329,13 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 l = rem % kCL; n = rem / kCL;
                 float v = 0.0f;
 #pragma unroll
-                for (int w = 0; w < kWPB; ++w) v += sdBC_[w][(isC ? kDC : 0) + n * kRowPitch + l];
+                for (int w = 0; w < kWPB; ++w) v += sdBC_[ch & 1][w][(isC ? kDC : 0) + n * kRowPitch + l];
                 if (n < N && l < len) {
                     float *base = isC ? dCb : dBb;
                     atomicAdd(base + (int64_t)(l0 + l) * (isC ? dC_sl : dB_sl) + n * (isC ? dC_sn : dB_sn), v);
                 }
             }
         }
-        __syncthreads();
         wave_sync();
     }
 
