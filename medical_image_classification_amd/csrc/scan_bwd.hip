@@ -216,21 +216,33 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         }
         // ---- reverse sweep: per batch, rebuild h of its 4 positions from the checkpoint and the stored a
         //      (mul + fma, no exp), then run the adjoint recurrence backwards over the window ---------------
+        // Operands of a batch (B/C rows, delta', u, dout of its 4 positions) are read from LDS ONE BATCH AHEAD, right before
+        // the previous batch's transpose-reduce (whose two LDS round trips then overlap with these loads instead of
+        // following them: the wave fences around the transpose keep the compiler from doing this itself).
+        float Bq[2][NPL][4], Cq[2][NPL][4], dq[2][4], uq[2][4], gq[2][4];
+        auto load_batch = [&](int kb) {
+            const int lb = kb * 4, pq = kb & 1;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                row4(sB + (sg * NPL + i) * kRowPitch, lb, Bq[pq][i]);
+                row4(sC + (sg * NPL + i) * kRowPitch, lb, Cq[pq][i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dq[pq][j] = sdl[(lb + j) * kPitch + c];
+                uq[pq][j] = su[(lb + j) * kPitch + c];
+                gq[pq][j] = sg_[(lb + j) * kPitch + c];
+            }
+        };
+        load_batch(NB - 1);
 #pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            float Bv[NPL][4], Cv[NPL][4];
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv[i]);
-                row4(sC + (sg * NPL + i) * kRowPitch, lb, Cv[i]);
-            }
-            float dl_[4], uu[4], gg[4], bu[4][NPL], hv[4][NPL];
+            float (&Bv)[NPL][4] = Bq[kb & 1], (&Cv)[NPL][4] = Cq[kb & 1];
+            float (&dl_)[4] = dq[kb & 1], (&uu)[4] = uq[kb & 1], (&gg)[4] = gq[kb & 1];
+            float bu[4][NPL], hv[4][NPL];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                dl_[j] = sdl[(lb + j) * kPitch + c];
-                uu[j] = su[(lb + j) * kPitch + c];
-                gg[j] = sg_[(lb + j) * kPitch + c];
                 const float du_ = dl_[j] * uu[j];
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
@@ -266,6 +278,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 su[lo * kPitch + c] = du_t;                // in place: this batch's u / dout are in registers
                 sg_[lo * kPitch + c] = dd_t;               // d delta' ; the softplus derivative is applied by the store
             }
+            if (kb > 0) load_batch(kb - 1);              // next batch's operands: in flight during the transpose below
             // sums over the wave's CW channels of the per-(position, state) dB / dC terms: transpose through LDS.
             // Lane (sg, c) writes its 4*NPL values into rows (r*SG + sg), column c (64 consecutive floats per r);
             // lane rr then reads row rr (CW consecutive floats), adds them and owns (position, state) = row_of(rr).
