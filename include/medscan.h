@@ -218,6 +218,10 @@ int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npi
 int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
                   int row_width, void *stream);
 
+/* Diagnostic: one workgroup busy for `cycles` (< 2^32) shader clocks on `stream` -- used to test whether two streams
+ * execute concurrently (medmamba.set_branch_streams). */
+int ms_spin(long long cycles, void *stream);
+
 int ms_abi_version(void);
 const char *ms_status_string(int status);
 

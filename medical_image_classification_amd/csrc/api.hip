@@ -150,6 +150,21 @@ int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, co
 
 int ms_bn_scratch_floats(int C) { return ms::bn_scratch_floats(C); }
 
+// One workgroup that keeps a CU busy for `cycles` shader clocks: a probe for whether two HIP streams really execute
+// concurrently (two probes take the time of one) or alias one hardware queue (the time of two).
+__global__ void ms_spin_kernel(long long cycles, int *sink) {
+    const long long t0 = clock64();
+    int acc = 0;
+    while (clock64() - t0 < cycles) acc += 1;
+    if (sink && threadIdx.x == 0 && acc == -1) *sink = acc;
+}
+
+int ms_spin(long long cycles, void *stream) {
+    if (cycles < 0 || cycles > (1LL << 32)) return MS_ERR_SHAPE;           // bounded: never a runaway kernel
+    hipLaunchKernelGGL(ms_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cycles, (int *)nullptr);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
 int ms_abi_version(void) { return MEDSCAN_ABI_VERSION; }
 
 const char *ms_status_string(int status) {

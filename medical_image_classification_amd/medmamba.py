@@ -54,10 +54,36 @@ def set_branch_streams(flag=True):
 
 
 def _side_stream(device):
+    """A stream that really executes concurrently with the current one.  HIP multiplexes streams onto a few hardware
+    queues; a stream that shares the current stream's queue is serialised behind it (observed: one of the first eight).
+    Each candidate is tested with two 100-us single-workgroup spin kernels (ms_spin): concurrent streams take the time of
+    one, aliased streams the time of two."""
     s = _SIDE_STREAMS.get(device.index)
-    if s is None:
-        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
-    return s
+    if s is not None:
+        return s
+    import ctypes
+    import time
+    lib = _lib.lib()
+    cur = torch.cuda.current_stream(device)
+    cyc = 240_000                                        # ~100 us
+    raw = lambda st: ctypes.c_void_p(st.cuda_stream)
+
+    def timed(fn):
+        torch.cuda.synchronize(device); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    solo = min(timed(lambda: lib.ms_spin(cyc, raw(cur))) for _ in range(3))
+    keep = []
+    for _ in range(8):
+        cand = torch.cuda.Stream(device=device)
+        keep.append(cand)                                # keep the rejected ones alive so the pool hands out new ones
+        both = min(timed(lambda: (lib.ms_spin(cyc, raw(cur)), lib.ms_spin(cyc, raw(cand)))) for _ in range(3))
+        if both < 1.5 * solo:
+            s = cand
+            break
+    _SIDE_STREAMS[device.index] = s if s is not None else keep[0]
+    _SIDE_STREAMS[("probed", device.index)] = keep
+    return _SIDE_STREAMS[device.index]
 
 
 def fused_block_forward(blk, input):
