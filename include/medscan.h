@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 3
+#define MEDSCAN_ABI_VERSION 4
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -142,13 +142,18 @@ int ms_dwconv3x3_silu_bwd(const float *x, const float *w, const float *bias, con
 /*
  * The same op on CHANNEL-LAST tensors (the layout in_proj produces; removes MedMamba.py:472's permute+copy):
  *   x : (batch, H, W, *) fp32 or bf16 (x_is_bf16), pixel stride `x_pixel_stride` elements, first C channels used
- *       (so the x half of xz = in_proj(x) is read in place);  y, dy, dx : (batch, H, W, C) contiguous fp32.
+ *       (so the x half of xz = in_proj(x) is read in place);  y : (batch, H, W, C) contiguous fp32.
+ *   bwd: the incoming gradient is the sum of `dy_ndir` contiguous (batch,H,W,C) fp32 slabs `dy_dir_stride` elements apart
+ *       (the scan's four per-direction du tensors are consumed as they are) plus `dy_extra` (same shape, or NULL);
+ *       dx : fp32 or bf16 with its own pixel stride (it can be written straight into the x half of the xz gradient);
+ *       scratch : (batch,H,W,C) fp32 workspace; dw (C,9) and dbias (C) are ACCUMULATED.
  */
 int ms_dwconv3x3_silu_nhwc_fwd(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
                                int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream);
-int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
-                               float *dx, float *scratch /* (batch,H,W,C) fp32 work buffer */, float *dw, float *dbias,
-                               int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream);
+int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int dy_ndir,
+                               int64_t dy_dir_stride, const float *dy_extra, void *dx, int dx_is_bf16, int64_t dx_pixel_stride,
+                               float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
+                               int64_t x_pixel_stride, void *stream);
 
 /*
  * Fused tail of SS2D (MedMamba.py:476-479): cross-merge sum of the four directions + LayerNorm(D) + SiLU gate.
@@ -163,7 +168,8 @@ int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_
                    int64_t npix, int D, void *stream);
 int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
                    const float *gamma, const float *beta, float eps, const void *dout, int dout_is_bf16,
-                   float *dy, void *dz, float *dgamma, float *dbeta, int64_t npix, int D, void *stream);
+                   float *dy, void *dz, int64_t dz_pixel_stride, float *dgamma, float *dbeta, int64_t npix, int D,
+                   void *stream);
 
 /* ---- the two-branch block around SS2D (SS_Conv_SSM, MedMamba.py:502-538) ------------------------------------
  * ms_layernorm_fwd/bwd replace `self.ln_1(right)` on the right half of `input.chunk(2, dim=-1)` (MedMamba.py:512-515):

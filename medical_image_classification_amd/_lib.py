@@ -51,7 +51,7 @@ EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks",
            "ms_dwconv3x3_silu_nhwc_bwd", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_bwd", "ms_bn_relu_nhwc_fwd",
            "ms_bn_relu_nhwc_bwd", "ms_bn_scratch_floats", "ms_spin", "ms_abi_version", "ms_status_string")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -90,10 +90,11 @@ def lib():
     h.ms_dwconv3x3_silu_fwd.argtypes = [c_vp] * 4 + [ctypes.c_int] * 4 + [c_vp]
     h.ms_dwconv3x3_silu_bwd.argtypes = [c_vp] * 7 + [ctypes.c_int] * 4 + [c_vp]
     h.ms_dwconv3x3_silu_nhwc_fwd.argtypes = [c_vp, ctypes.c_int] + [c_vp] * 3 + [ctypes.c_int] * 4 + [c_i64, c_vp]
-    h.ms_dwconv3x3_silu_nhwc_bwd.argtypes = [c_vp, ctypes.c_int] + [c_vp] * 7 + [ctypes.c_int] * 4 + [c_i64, c_vp]
+    h.ms_dwconv3x3_silu_nhwc_bwd.argtypes = ([c_vp, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, ctypes.c_int,
+                                              c_i64, c_vp, c_vp, c_vp] + [ctypes.c_int] * 4 + [c_i64, c_vp])
     c_f, c_int = ctypes.c_float, ctypes.c_int
     h.ms_ln_gate_fwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_i64, c_int, c_vp]
-    h.ms_ln_gate_bwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
+    h.ms_ln_gate_bwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp,
                                  c_i64, c_int, c_vp]
     h.ms_layernorm_fwd.argtypes = [c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_i64, c_int, c_vp]
     h.ms_layernorm_bwd.argtypes = [c_vp, c_i64, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]

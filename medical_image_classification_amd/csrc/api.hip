@@ -14,13 +14,13 @@ int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const
                         float *dw, float *dbias, int batch, int C, int H, int W, hipStream_t s);
 int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
                              int batch, int C, int H, int W, int64_t xps, hipStream_t s);
-int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
-                             float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
-                             int64_t xps, hipStream_t s);
+int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int ndir,
+                             int64_t dir_stride, const float *dy_extra, void *dx, int dx_bf16, int64_t dxps, float *scratch,
+                             float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s);
 int ln_gate_fwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
                          const float *beta, float eps, void *out, int out_bf16, int64_t npix, int D, hipStream_t s);
 int ln_gate_bwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
-                         const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz,
+                         const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz, int64_t dzps,
                          float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
 int block_tail_fwd_dispatch(const void *left, int left_is_bf16, const void *x, int x_is_bf16, const float *input,
                             const float *scale, float *out, int64_t npix, int64_t hw, int C, hipStream_t s);
@@ -79,11 +79,13 @@ int ms_dwconv3x3_silu_nhwc_fwd(const void *x, int x_is_bf16, const float *w, con
     return ms::dwconv_nhwc_fwd_dispatch(x, x_is_bf16, w, bias, y, batch, C, H, W, x_pixel_stride, (hipStream_t)stream);
 }
 
-int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
-                               float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
+int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int dy_ndir,
+                               int64_t dy_dir_stride, const float *dy_extra, void *dx, int dx_is_bf16, int64_t dx_pixel_stride,
+                               float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
                                int64_t x_pixel_stride, void *stream) {
-    return ms::dwconv_nhwc_bwd_dispatch(x, x_is_bf16, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W,
-                                        x_pixel_stride, (hipStream_t)stream);
+    return ms::dwconv_nhwc_bwd_dispatch(x, x_is_bf16, w, bias, dy, dy_ndir, dy_dir_stride, dy_extra, dx, dx_is_bf16,
+                                        dx_pixel_stride, scratch, dw, dbias, batch, C, H, W, x_pixel_stride,
+                                        (hipStream_t)stream);
 }
 
 int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
@@ -95,9 +97,10 @@ int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_
 
 int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
                    const float *gamma, const float *beta, float eps, const void *dout, int dout_is_bf16,
-                   float *dy, void *dz, float *dgamma, float *dbeta, int64_t npix, int D, void *stream) {
+                   float *dy, void *dz, int64_t dz_pixel_stride, float *dgamma, float *dbeta, int64_t npix, int D,
+                   void *stream) {
     return ms::ln_gate_bwd_dispatch(y4, dir_stride, z, z_is_bf16, z_pixel_stride, gamma, beta, eps, dout, dout_is_bf16,
-                                    dy, dz, dgamma, dbeta, npix, D, (hipStream_t)stream);
+                                    dy, dz, dz_pixel_stride, dgamma, dbeta, npix, D, (hipStream_t)stream);
 }
 
 int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_is_bf16, const float *input,

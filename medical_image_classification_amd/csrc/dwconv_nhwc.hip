@@ -20,6 +20,9 @@ template <> __device__ __forceinline__ float ldf<unsigned short>(const unsigned 
     return __builtin_bit_cast(float, (unsigned)(*p) << 16);
 }
 
+__device__ __forceinline__ void stf(float *p, float v) { *p = v; }
+__device__ __forceinline__ void stf(unsigned short *p, float v) { *p = __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 dwconv_nhwc_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
@@ -75,7 +78,8 @@ constexpr int kRowsPerWaveBwd1 = 2;      // rows per wave in pass 1; with the 4-
 template <typename T>
 __global__ void __launch_bounds__(256)
 dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                        const float *__restrict__ dy, float *__restrict__ dpre, float *__restrict__ dw,
+                        const float *__restrict__ dy, int ndir, int64_t dir_stride, const float *__restrict__ dy_extra,
+                        float *__restrict__ dpre, float *__restrict__ dw,
                         float *__restrict__ dbias, int C, int H, int W, int64_t xps, int rows) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     __shared__ float red[3][10][64];
@@ -113,7 +117,13 @@ dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, co
                 const int64_t o = (int64_t)(in ? wn : W - 1) * xps;
                 const float t0 = ldf(r0v + o), t1 = ldf(r1 + o), t2 = ldf(r2v + o);
                 n0[q] = (in && v0) ? t0 : 0.0f; n1[q] = in ? t1 : 0.0f; n2[q] = (in && v2) ? t2 : 0.0f;
-                gq[q] = go[(int64_t)min(w0 + q, W - 1) * C];
+                // the incoming gradient may arrive as `ndir` slabs (the scan's four per-direction du) plus one more term
+                // (the x_proj backward): summed here instead of by separate reduce / add kernels
+                const int64_t gi = (int64_t)min(w0 + q, W - 1) * C;
+                float gs = go[gi];
+                for (int kd = 1; kd < ndir; ++kd) gs += go[gi + kd * dir_stride];
+                if (dy_extra) gs += dy_extra[(int64_t)row * W * C + cc + gi];
+                gq[q] = gs;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -152,8 +162,9 @@ dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, co
 
 // Backward, pass 2: dx = conv3x3^T(dpre): dx[h][w] = sum_{i,j} dpre[h+1-i][w+1-j] * k[i][j]  (a correlation with the
 // flipped kernel: again a 3-row sliding window).
+template <typename TO>
 __global__ void __launch_bounds__(256)
-dwconv_nhwc_bwd2_kernel(const float *__restrict__ dpre, const float *__restrict__ w, float *__restrict__ dx,
+dwconv_nhwc_bwd2_kernel(const float *__restrict__ dpre, const float *__restrict__ w, TO *__restrict__ dx, int64_t dxps,
                         int C, int H, int W, int rows) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -170,7 +181,7 @@ dwconv_nhwc_bwd2_kernel(const float *__restrict__ dpre, const float *__restrict_
     const float *r0v = v0 ? r0 : r1, *r2v = v2 ? r2 : r1;
     float a0 = 0, a1 = 0, a2 = 0, b0, b1, b2;                     // dpre columns w-1 (a), w (b); rows h-1,h,h+1
     b0 = v0 ? r0[0] : 0.0f; b1 = r1[0]; b2 = v2 ? r2[0] : 0.0f;
-    float *xo = dx + (int64_t)row * W * C + c;
+    TO *xo = dx + (int64_t)row * W * dxps + c;                    // dx may be a channel slice of a wider gradient tensor
     for (int w0 = 0; w0 < W; w0 += 4) {                            // 4 columns per trip, 12 loads in flight
         float n0[4], n1[4], n2[4];
 #pragma unroll
@@ -190,7 +201,7 @@ dwconv_nhwc_bwd2_kernel(const float *__restrict__ dpre, const float *__restrict_
                 a = fmaf(k[0], c2, a); a = fmaf(k[1], b2, a); a = fmaf(k[2], a2, a);
                 a = fmaf(k[3], c1, a); a = fmaf(k[4], b1, a); a = fmaf(k[5], a1, a);
                 a = fmaf(k[6], c0, a); a = fmaf(k[7], b0, a); a = fmaf(k[8], a0, a);
-                if (cv) xo[(int64_t)(w0 + q) * C] = a;
+                if (cv) stf(xo + (int64_t)(w0 + q) * dxps, a);
                 a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
             }
         }
@@ -216,27 +227,29 @@ int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const
 }
 
 template <typename T>
-static int launch_bwd(const void *x, const float *w, const float *bias, const float *dy, float *dx, float *scratch,
-                      float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s) {
+static int launch_bwd(const void *x, const float *w, const float *bias, const float *dy, int ndir, int64_t dir_stride,
+                      const float *dy_extra, void *dx, int dx_bf16, int64_t dxps, float *scratch, float *dw, float *dbias,
+                      int batch, int C, int H, int W, int64_t xps, hipStream_t s) {
     const int rows = batch * H;
     // dx doubles as the dpre scratch of pass 1?  No: pass 2 reads rows h-1..h+1 of dpre while writing row h of dx,
-    // so dpre needs its own buffer -- the caller passes it in `dx_scratch` (same shape as dx).
+    // so dpre needs its own buffer -- the caller passes it in `scratch` ((batch, H, W, C) fp32).
     const int tasks = (rows + kRowsPerWaveBwd1 - 1) / kRowsPerWaveBwd1;
     hipLaunchKernelGGL((dwconv_nhwc_bwd1_kernel<T>), dim3((C + 63) / 64, (tasks + 3) / 4, 1), dim3(256), 0, s,
-                       (const T *)x, w, bias, dy, scratch, dw, dbias, C, H, W, xps, rows);
-    hipLaunchKernelGGL((dwconv_nhwc_bwd2_kernel), dim3((C + 63) / 64, (rows + 3) / 4, 1), dim3(256), 0, s,
-                       scratch, w, dx, C, H, W, rows);
+                       (const T *)x, w, bias, dy, ndir, dir_stride, dy_extra, scratch, dw, dbias, C, H, W, xps, rows);
+    const dim3 g2((C + 63) / 64, (rows + 3) / 4, 1);
+    if (dx_bf16) hipLaunchKernelGGL((dwconv_nhwc_bwd2_kernel<unsigned short>), g2, dim3(256), 0, s, scratch, w, (unsigned short *)dx, dxps, C, H, W, rows);
+    else         hipLaunchKernelGGL((dwconv_nhwc_bwd2_kernel<float>), g2, dim3(256), 0, s, scratch, w, (float *)dx, dxps, C, H, W, rows);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
-int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy,
-                             float *dx, float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
-                             int64_t xps, hipStream_t s) {
+int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int ndir,
+                             int64_t dir_stride, const float *dy_extra, void *dx, int dx_bf16, int64_t dxps, float *scratch,
+                             float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s) {
     if (!x || !w || !dy || !dx || !dw || !scratch) return MS_ERR_NULL;
-    if (batch < 0 || C <= 0 || H <= 0 || W <= 0 || xps < C) return MS_ERR_SHAPE;
+    if (batch < 0 || C <= 0 || H <= 0 || W <= 0 || xps < C || dxps < C || ndir < 1 || ndir > 8) return MS_ERR_SHAPE;
     if (batch == 0) return MS_OK;
-    return x_is_bf16 ? launch_bwd<unsigned short>(x, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W, xps, s)
-                     : launch_bwd<float>(x, w, bias, dy, dx, scratch, dw, dbias, batch, C, H, W, xps, s);
+    return x_is_bf16 ? launch_bwd<unsigned short>(x, w, bias, dy, ndir, dir_stride, dy_extra, dx, dx_bf16, dxps, scratch, dw, dbias, batch, C, H, W, xps, s)
+                     : launch_bwd<float>(x, w, bias, dy, ndir, dir_stride, dy_extra, dx, dx_bf16, dxps, scratch, dw, dbias, batch, C, H, W, xps, s);
 }
 
 }  // namespace ms

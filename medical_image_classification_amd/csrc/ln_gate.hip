@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256)
 ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restrict__ z, int64_t zps,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                    const TG *__restrict__ dout, float *__restrict__ dy, TZ *__restrict__ dz,
-                   float *__restrict__ dgamma, float *__restrict__ dbeta, int D, int64_t npix) {
+                   float *__restrict__ dgamma, float *__restrict__ dbeta, int D, int64_t npix, int64_t dzps) {
     __shared__ float red[3][2][kMaxVPT * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float gm[VPT], bt[VPT], dg[VPT], db[VPT];
@@ -133,7 +133,7 @@ ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
                 const float sg = 1.0f / (1.0f + expf(-zz[q][j]));
                 const float yn = in ? (y[q][j] - s1[q]) * rstd : 0.0f;
                 const float yh = yn * gm[j] + bt[j];
-                if (in && live) st(dz + (p0 + q) * D + c, g[q][j] * yh * (sg * (1.0f + zz[q][j] * (1.0f - sg))));
+                if (in && live) st(dz + (p0 + q) * dzps + c, g[q][j] * yh * (sg * (1.0f + zz[q][j] * (1.0f - sg))));
                 const float dyh = in ? g[q][j] * (zz[q][j] * sg) : 0.0f;
                 if (live) { dg[j] = fmaf(dyh, yn, dg[j]); db[j] += dyh; }
                 y[q][j] = yn;                                    // y <- normalised value
@@ -199,7 +199,7 @@ int ln_gate_fwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16,
 
 template <typename TZ, typename TG>
 static int launch_bwd(const float *y4, int64_t sk, const void *z, int64_t zps, const float *gamma, const float *beta,
-                      float eps, const void *dout, float *dy, void *dz, float *dgamma, float *dbeta, int D,
+                      float eps, const void *dout, float *dy, void *dz, int64_t dzps, float *dgamma, float *dbeta, int D,
                       int64_t npix, hipStream_t s) {
     const int vpt = (D + 63) / 64;
     const int pb = vpt <= 2 ? 4 : vpt <= 4 ? 2 : 1;                 // = MS_PB of the dispatched VPT bucket
@@ -208,7 +208,7 @@ static int launch_bwd(const float *y4, int64_t sk, const void *z, int64_t zps, c
     const int64_t cap = npix >= 32768 ? 1024 : 512;      // measured optimum (tools/bench_ln.py), see ln.hip
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap)), block(256);      // persistent
 #define MS_PB(V) ((V) <= 2 ? 4 : (V) <= 4 ? 2 : 1)
-#define MS_L(V) hipLaunchKernelGGL((ln_gate_bwd_kernel<V, MS_PB(V), TZ, TG>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix)
+#define MS_L(V) hipLaunchKernelGGL((ln_gate_bwd_kernel<V, MS_PB(V), TZ, TG>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix, dzps)
     if (vpt <= 1) MS_L(1); else if (vpt <= 2) MS_L(2); else if (vpt <= 3) MS_L(3); else if (vpt <= 4) MS_L(4);
     else if (vpt <= 6) MS_L(6); else if (vpt <= 8) MS_L(8); else if (vpt <= 12) MS_L(12); else MS_L(16);
 #undef MS_L
@@ -217,15 +217,15 @@ static int launch_bwd(const float *y4, int64_t sk, const void *z, int64_t zps, c
 }
 
 int ln_gate_bwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
-                         const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz,
+                         const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz, int64_t dzps,
                          float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s) {
     if (!y4 || !z || !gamma || !beta || !dout || !dy || !dz || !dgamma || !dbeta) return MS_ERR_NULL;
-    if (D <= 0 || D > 64 * kMaxVPT || npix < 0 || zps < D) return MS_ERR_SHAPE;
+    if (D <= 0 || D > 64 * kMaxVPT || npix < 0 || zps < D || dzps < D) return MS_ERR_SHAPE;
     if (npix == 0) return MS_OK;
-    if (z_bf16) return dout_bf16 ? launch_bwd<unsigned short, unsigned short>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dgamma, dbeta, D, npix, s)
-                                 : launch_bwd<unsigned short, float>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dgamma, dbeta, D, npix, s);
-    return dout_bf16 ? launch_bwd<float, unsigned short>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dgamma, dbeta, D, npix, s)
-                     : launch_bwd<float, float>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dgamma, dbeta, D, npix, s);
+    if (z_bf16) return dout_bf16 ? launch_bwd<unsigned short, unsigned short>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dzps, dgamma, dbeta, D, npix, s)
+                                 : launch_bwd<unsigned short, float>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dzps, dgamma, dbeta, D, npix, s);
+    return dout_bf16 ? launch_bwd<float, unsigned short>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dzps, dgamma, dbeta, D, npix, s)
+                     : launch_bwd<float, float>(y4, sk, z, zps, gamma, beta, eps, dout, dy, dz, dzps, dgamma, dbeta, D, npix, s);
 }
 
 }  // namespace ms

@@ -23,7 +23,7 @@ import torch.utils.checkpoint as checkpoint
 from . import _lib
 from .block_ops import block_tail, conv_branch, layernorm_rows, split_halves
 from .selective_scan_interface import selective_scan_fn
-from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate
+from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate, ss2d_inner
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_splitk
 
 # The channel-last fused core is the default path of SS2D.forward; MEDSCAN_FUSED=0 selects the layout-faithful path
@@ -34,6 +34,8 @@ FUSED = os.environ.get("MEDSCAN_FUSED", "1") != "0"
 CONV_CHANNELS_LAST = os.environ.get("MEDSCAN_CONV_CL", "1") == "1"
 # SS_Conv_SSM: in-place LayerNorm of the right half + one-pass cat/shuffle/drop-path/residual tail (block_ops.py)
 BLOCK_FUSED = os.environ.get("MEDSCAN_BLOCK_FUSED", "1") == "1"
+# SS2D: conv -> x_proj -> dt_proj -> scan -> norm/gate as one autograd node (ss2d_fused._SS2DInner); 0 = one node per op
+SS2D_NODE = os.environ.get("MEDSCAN_SS2D_NODE", "1") == "1"
 # SS_Conv_SSM: optionally run the conv branch on a side HIP stream, concurrently with the LayerNorm + SS2D branch (the
 # branches are independent until the tail).  OPT-IN: measured on MedMamba-T bs 64 it takes the step from 27.0 ms to
 # 24-25 ms in most processes but to 28-31 ms in others (same build, same box -- which hardware queue the side stream lands
@@ -299,9 +301,14 @@ class SS2D(nn.Module):
         _lib.require_cuda(x)
         B, H, W, C = x.shape
         xz = linear_splitk(x, self.in_proj.weight) if self.in_proj.bias is None else self.in_proj(x)
-        x, z = split_halves(xz) if xz.is_cuda else xz.chunk(2, dim=-1)   # (B,H,W,D) views of xz; one concat in backward
         default_core = getattr(self.forward_core, "__func__", None) is SS2D.forward_corev0
-        if FUSED and default_core and self.d_conv == 3 and type(self.out_norm) is nn.LayerNorm and self.d_inner <= 1024:
+        fused_tail = FUSED and default_core and self.d_conv == 3 and type(self.out_norm) is nn.LayerNorm and self.d_inner <= 1024
+        if fused_tail and SS2D_NODE and xz.is_cuda:
+            yg = ss2d_inner(xz, self)
+            out = linear_splitk(yg, self.out_proj.weight) if self.out_proj.bias is None else self.out_proj(yg)
+            return out if self.dropout is None else self.dropout(out)
+        x, z = split_halves(xz) if xz.is_cuda else xz.chunk(2, dim=-1)   # (B,H,W,D) views of xz; one concat in backward
+        if fused_tail:
             # channel-last fused core: the conv reads xz in place, the scan kernel applies the 4 direction maps itself,
             # merge + out_norm + SiLU(z) gate are one kernel
             xc = dwconv3x3_silu_nhwc(x, self.conv2d.weight, self.conv2d.bias)

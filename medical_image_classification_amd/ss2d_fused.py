@@ -56,8 +56,9 @@ class _DWConvSiLUNHWC(torch.autograd.Function):
         with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr() if b is not None else None,
-                dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
-                B, C, H, W, ctx.ps, _lib.current_stream_ptr(x.device)), "ms_dwconv3x3_silu_nhwc_bwd")
+                dy.data_ptr(), 1, 0, None, dx.data_ptr(), 0, C, scratch.data_ptr(), dw.data_ptr(),
+                db.data_ptr() if db is not None else None, B, C, H, W, ctx.ps, _lib.current_stream_ptr(x.device)),
+                "ms_dwconv3x3_silu_nhwc_bwd")
         return dx.to(x.dtype), dw.to(ctx.wdtype), (db.to(ctx.bdtype) if db is not None else None)
 
 
@@ -271,7 +272,7 @@ class _SS2DScanNormGate(torch.autograd.Function):
         with _lib.on_device(xc.device):
             _lib.check(lib.ms_ln_gate_bwd(y4.data_ptr(), B * L * D, z.data_ptr(), int(z.dtype == torch.bfloat16), zps,
                                           gamma.data_ptr(), beta.data_ptr(), eps, dout.data_ptr(),
-                                          int(dout.dtype == torch.bfloat16), dy.data_ptr(), dz.data_ptr(),
+                                          int(dout.dtype == torch.bfloat16), dy.data_ptr(), dz.data_ptr(), D,
                                           dgamma.data_ptr(), dbeta.data_ptr(), B * L, D, stream), "ms_ln_gate_bwd")
             rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), xc.device,
                               lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream))
@@ -280,6 +281,133 @@ class _SS2DScanNormGate(torch.autograd.Function):
         dxc = du4.sum(dim=0).view_as(xc)
         return (dxc, dproj, (None if ctx.has_wdt else ddelta), dwdt, dA, dD, dbias, dz, dgamma, dbeta,
                 None, None, None, None, None, None)
+
+
+class _SS2DInner(torch.autograd.Function):
+    """Everything between in_proj and out_proj of SS2D (MedMamba.py:469-479) as ONE autograd node:
+    depthwise conv + SiLU -> x_proj -> dt_proj -> 4-direction scan -> merge + out_norm + SiLU(z) gate.
+    Backward hands gradients from kernel to kernel without autograd glue: the scan's four per-direction du slabs and the
+    x_proj input gradient are summed inside the conv backward's load (no du4.sum, no gradient add), and the conv's dx and
+    the gate's dz are written (in xz's dtype) straight into the two halves of ONE (B,H,W,2D) gradient buffer (no casts, no
+    concat)."""
+
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, xproj_w, wdt, A_logs, Ds, dt_bias, gamma, beta, eps, N, R, out_bf16, mm_dtype):
+        _lib.require_cuda(xz, conv_w, xproj_w, wdt, A_logs, Ds, dt_bias, gamma, beta)
+        lib = _lib.lib()
+        B, H, W, D2 = xz.shape
+        D, L, M, C = D2 // 2, H * W, B * H * W, R + 2 * N
+        if xz.dtype not in (torch.float32, torch.bfloat16):
+            xz = xz.float()
+        xz = xz.contiguous()
+        isz, xz_bf16 = xz.element_size(), int(xz.dtype == torch.bfloat16)
+        f32 = lambda t: t.detach().float().contiguous()
+        cw, cb = f32(conv_w), (f32(conv_b) if conv_b is not None else None)
+        wdt, A, Dv, bias, gamma, beta = f32(wdt), f32(A_logs), f32(Ds), f32(dt_bias), f32(gamma), f32(beta)
+        wx = xproj_w.detach().reshape(4 * C, D)
+        wx = (wx.to(mm_dtype) if mm_dtype is not None else wx.float()).contiguous()
+        dev = xz.device
+        xc = torch.empty((B, H, W, D), device=dev, dtype=torch.float32)
+        y4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
+        x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=dev, dtype=torch.float32)
+        out = torch.empty((B, H, W, D), device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        stream = _lib.current_stream_ptr(dev)
+        with _lib.on_device(dev):
+            _lib.check(lib.ms_dwconv3x3_silu_nhwc_fwd(xz.data_ptr(), xz_bf16, cw.data_ptr(), cb.data_ptr() if cb is not None else None,
+                                                      xc.data_ptr(), B, D, H, W, D2, stream), "ms_dwconv3x3_silu_nhwc_fwd")
+            xm = xc.view(M, D).to(mm_dtype) if mm_dtype is not None else xc.view(M, D)
+            proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())   # (M, 4C)
+            delta = _dtproj_fwd(proj, wdt, B, L, D, R, C)
+            P = MsScanParams()
+            _ss2d_params(P, xc, proj, delta, A, Dv, bias, y4, x_state, H, W, N, R, a_is_log=True)
+            rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), dev,
+                              lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
+            _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
+            _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
+                                          beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), M, D, stream),
+                       "ms_ln_gate_fwd")
+        ctx.save_for_backward(xz, xc, xm if mm_dtype is not None else None, wx, proj, delta, x_state, y4, cw, cb, wdt, A, Dv, bias,
+                              gamma, beta)
+        ctx.geom = (N, R, float(eps))
+        ctx.dtypes = (conv_w.dtype, conv_b.dtype if conv_b is not None else None, xproj_w.dtype, xproj_w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xz, xc, xm, wx, proj, delta, x_state, y4, cw, cb, wdt, A, Dv, bias, gamma, beta = ctx.saved_tensors
+        N, R, eps = ctx.geom
+        lib = _lib.lib()
+        B, H, W, D2 = xz.shape
+        D, L, M, C = D2 // 2, H * W, B * H * W, R + 2 * N
+        dev = xz.device
+        isz, xz_bf16 = xz.element_size(), int(xz.dtype == torch.bfloat16)
+        if dout.dtype not in (torch.float32, torch.bfloat16):
+            dout = dout.float()
+        dout = dout.contiguous()
+        dxz = torch.empty_like(xz)
+        dy = torch.empty((B, L, D), device=dev, dtype=torch.float32)
+        du4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
+        ddelta = torch.empty_like(du4)
+        dproj = torch.zeros_like(proj)
+        scratch = torch.empty_like(xc)
+        sizes = (A.numel(), Dv.numel(), bias.numel(), gamma.numel(), beta.numel(), cw.numel(), cb.numel() if cb is not None else 0)
+        zbuf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        dA, dD, dbias, dgamma, dbeta, dcw, dcb = zbuf.split(sizes)
+        Q = MsScanBwdParams()
+        _ss2d_params(Q.f, xc, proj, delta, A, Dv, bias, None, x_state, H, W, N, R, a_is_log=True)
+        Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
+        Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, B * L * D, 1, D
+        Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * D, B * L * D, 1, D
+        Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = L * 4 * C, C, 1, 4 * C
+        Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = L * 4 * C, C, 1, 4 * C
+        Q.dout, Q.du, Q.ddelta = dy.data_ptr(), du4.data_ptr(), ddelta.data_ptr()
+        Q.dA, Q.dD, Q.ddelta_bias = dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
+        Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
+        stream = _lib.current_stream_ptr(dev)
+        with _lib.on_device(dev):
+            _lib.check(lib.ms_ln_gate_bwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
+                                          beta.data_ptr(), eps, dout.data_ptr(), int(dout.dtype == torch.bfloat16),
+                                          dy.data_ptr(), dxz.data_ptr() + D * isz, D2, dgamma.data_ptr(), dbeta.data_ptr(),
+                                          M, D, stream), "ms_ln_gate_bwd")
+            rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), dev,
+                              lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream))
+            _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
+            dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C)
+            # x_proj backward: input gradient in fp32 straight out of the GEMM, split-K weight gradient
+            dpm = dproj.view(M, 4 * C)
+            if xm is not None:
+                dpm = dpm.to(xm.dtype)
+                dxe = torch.mm(dpm, wx, out_dtype=torch.float32)
+            else:
+                xm = xc.view(M, D)
+                dxe = torch.mm(dpm, wx)
+            S = _split_k(M)
+            if S > 1:
+                a, b = dpm.view(S, M // S, 4 * C).transpose(1, 2), xm.view(S, M // S, D)
+                dwx = (torch.bmm(a, b, out_dtype=torch.float32) if xm.dtype != torch.float32 else torch.bmm(a, b)).sum(dim=0)
+            else:
+                dwx = torch.mm(dpm.t(), xm).float()
+            _lib.check(lib.ms_dwconv3x3_silu_nhwc_bwd(
+                xz.data_ptr(), xz_bf16, cw.data_ptr(), cb.data_ptr() if cb is not None else None, du4.data_ptr(), 4, B * L * D,
+                dxe.data_ptr(), dxz.data_ptr(), xz_bf16, D2, scratch.data_ptr(), dcw.data_ptr(),
+                dcb.data_ptr() if cb is not None else None, B, D, H, W, D2, stream), "ms_dwconv3x3_silu_nhwc_bwd")
+        cwd, cbd, wxd, wxs = ctx.dtypes
+        return (dxz, dcw.view(cw.shape).to(cwd), (dcb.to(cbd) if cb is not None else None), dwx.view(wxs).to(wxd), dwdt,
+                dA.view(A.shape), dD, dbias, dgamma, dbeta, None, None, None, None, None)
+
+
+def ss2d_inner(xz, mod):
+    """xz = in_proj(x) (B,H,W,2*d_inner) -> out_norm(merge(scan(conv(x)))) * silu(z), (B,H,W,d_inner), ready for out_proj
+    (bf16 under bf16 autocast, else fp32).  `mod` is the SS2D module (parameters)."""
+    ac = torch.is_autocast_enabled()
+    mm_dtype = torch.get_autocast_dtype("cuda") if ac else None
+    if mm_dtype == torch.float32:
+        mm_dtype = None
+    out_bf16 = mm_dtype == torch.bfloat16
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _SS2DInner.apply(xz, mod.conv2d.weight, mod.conv2d.bias, mod.x_proj_weight, mod.dt_projs_weight, mod.A_logs,
+                                mod.Ds.view(-1), mod.dt_projs_bias.view(-1), mod.out_norm.weight, mod.out_norm.bias,
+                                mod.out_norm.eps, mod.d_state, mod.dt_rank, out_bf16, mm_dtype)
 
 
 def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):

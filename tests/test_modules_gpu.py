@@ -216,19 +216,83 @@ def test_fused_core_matches_layout_faithful_path(cfg, monkeypatch):
     x = torch.randn(B, H, W, d_model, device=dev())
     g = torch.randn(B, H, W, d_model, device=dev())
     outs = []
-    for fused in (True, False):
+    # one autograd node for the whole inner path / one node per op / reference layout
+    for fused, node in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(mm, "FUSED", fused)
+        monkeypatch.setattr(mm, "SS2D_NODE", node)
         blk.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_()
         y = blk(xi)
         y.backward(g)
         outs.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
-    (yf, dxf, gf), (yu, dxu, gu) = outs
+    yu, dxu, gu = outs[2]
     sc = lambda t: max(1e-3, float(t.abs().max()))
-    assert float((yf - yu).abs().max()) <= 1e-4 * sc(yu)
-    assert float((dxf - dxu).abs().max()) <= 5e-4 * sc(dxu)
-    for k in gu:
-        assert float((gf[k] - gu[k]).abs().max()) <= 2e-3 * sc(gu[k]), k
+    for yf, dxf, gf in outs[:2]:
+        assert float((yf - yu).abs().max()) <= 1e-4 * sc(yu)
+        assert float((dxf - dxu).abs().max()) <= 5e-4 * sc(dxu)
+        for k in gu:
+            assert float((gf[k] - gu[k]).abs().max()) <= 2e-3 * sc(gu[k]), k
+
+
+@pytest.mark.parametrize("cfg", [(16, 6, 9, 2), (96, 28, 28, 2), (12, 5, 7, 3)])
+def test_ss2d_single_node_bf16_autocast_matches_per_op_nodes(cfg, monkeypatch):
+    """Under bf16 autocast the one-node SS2D inner path (gradients handed kernel to kernel, dx/dz written as bf16 into one
+    xz gradient) == the per-op autograd path to bf16 rounding."""
+    from medical_image_classification_amd import medmamba as mm
+    d_model, H, W, B = cfg
+    torch.manual_seed(d_model * H)
+    blk = mm.SS2D(d_model=d_model).to(dev())
+    x = torch.randn(B, H, W, d_model, device=dev())
+    g = torch.randn(B, H, W, d_model, device=dev())
+    outs = []
+    for node in (True, False):
+        monkeypatch.setattr(mm, "SS2D_NODE", node)
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xi)
+        y.float().backward(g)
+        outs.append((y.detach().float(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    (yn, dxn, gn), (yo, dxo, go) = outs
+    sc = lambda t: max(1e-3, float(t.abs().max()))
+    assert yn.shape == yo.shape
+    assert float((yn - yo).abs().max()) <= 2e-2 * sc(yo)
+    assert float((dxn - dxo).abs().max()) <= 3e-2 * sc(dxo)
+    for k in go:
+        assert float((gn[k] - go[k]).abs().max()) <= 3e-2 * sc(go[k]), k
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_dwconv_nhwc_bwd_sums_direction_slabs_and_writes_strided_dx(bf16):
+    """ms_dwconv3x3_silu_nhwc_bwd with 4 gradient slabs + an extra term, dx written (typed) into the left half of a wider
+    buffer: equals torch autograd of silu(conv2d) fed the summed gradient; the right half of the buffer is untouched."""
+    from medical_image_classification_amd import _lib
+    B, H, W, C = 2, 9, 11, 24
+    gen = torch.Generator().manual_seed(7)
+    xz = torch.randn(B, H, W, 2 * C, generator=gen)
+    if bf16:
+        xz = xz.bfloat16().float()
+    w = torch.randn(C, 1, 3, 3, generator=gen) * 0.3; b = torch.randn(C, generator=gen) * 0.1
+    g4 = torch.randn(4, B, H, W, C, generator=gen); ge = torch.randn(B, H, W, C, generator=gen)
+    xr = xz[..., :C].permute(0, 3, 1, 2).double().requires_grad_()
+    wr, br = w.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.silu(F.conv2d(xr, wr, br, padding=1, groups=C))
+    ref.backward((g4.sum(0) + ge).permute(0, 3, 1, 2).double())
+    d = dev(); dt = torch.bfloat16 if bf16 else torch.float32
+    xzd, wd, bd, g4d, ged = xz.to(d, dt), w.to(d).contiguous(), b.to(d), g4.to(d), ge.to(d)
+    dxz = torch.full((B, H, W, 2 * C), 7.0, device=d, dtype=dt)
+    scratch = torch.empty(B, H, W, C, device=d); dw = torch.zeros(C, 9, device=d); db = torch.zeros(C, device=d)
+    _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd(
+        xzd.data_ptr(), int(bf16), wd.data_ptr(), bd.data_ptr(), g4d.data_ptr(), 4, B * H * W * C, ged.data_ptr(),
+        dxz.data_ptr(), int(bf16), 2 * C, scratch.data_ptr(), dw.data_ptr(), db.data_ptr(), B, C, H, W, 2 * C,
+        _lib.current_stream_ptr(d)), "bwd")
+    tol = 2e-2 if bf16 else 1e-4
+    sc = max(1.0, float(xr.grad.abs().max()))
+    assert_close(dxz[..., :C].float(), xr.grad.permute(0, 2, 3, 1).numpy(), tol, tol * sc, "dx")
+    assert bool((dxz[..., C:] == 7.0).all())
+    scw = max(1.0, float(wr.grad.abs().max()))
+    assert_close(dw.view(C, 1, 3, 3), wr.grad.numpy(), 1e-4, 1e-4 * scw, "dw")
+    assert_close(db, br.grad.numpy(), 1e-4, 1e-4 * scw, "db")
 
 
 @pytest.mark.parametrize("cfg", [(2, 6, 9, 96), (1, 7, 7, 768), (3, 2, 5, 70), (1, 1, 1, 130), (2, 4, 4, 1024)])
@@ -264,8 +328,8 @@ def test_ln_gate_kernels_vs_torch(cfg, bf16):
     dy = torch.empty(npix, D, device=d); dz = torch.empty(npix, D, device=d, dtype=dt)
     dgam, dbet = torch.zeros(D, device=d), torch.zeros(D, device=d)
     _lib.check(lib.ms_ln_gate_bwd(y4d.data_ptr(), npix * D, zptr, int(bf16), 2 * D, gamd.data_ptr(), betd.data_ptr(), 1e-5,
-                                  gd.data_ptr(), int(bf16), dy.data_ptr(), dz.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
-                                  npix, D, st), "bwd")
+                                  gd.data_ptr(), int(bf16), dy.data_ptr(), dz.data_ptr(), D, dgam.data_ptr(),
+                                  dbet.data_ptr(), npix, D, st), "bwd")
     for k in range(4):                                   # every direction receives the same dy
         assert_close(dy, y4r.grad[k].numpy(), 1e-3, 1e-4 * max(1.0, float(y4r.grad.abs().max())), f"dy{k}")
     assert_close(dz, zr.grad.numpy(), tol, tol * max(1.0, float(zr.grad.abs().max())), "dz")

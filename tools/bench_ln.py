@@ -24,7 +24,7 @@ for D, Hh in [(96, 56), (192, 28), (384, 14), (768, 7)]:
     dy = torch.empty(npix, D, device=dev); dz = torch.empty_like(z); dgb = torch.zeros(2, D, device=dev)
     f = lambda: h.ms_ln_gate_fwd(y4.data_ptr(), npix * D, z.data_ptr(), 1, D, gm.data_ptr(), bt.data_ptr(), 1e-5, out.data_ptr(), 1, npix, D, st())
     b = lambda: h.ms_ln_gate_bwd(y4.data_ptr(), npix * D, z.data_ptr(), 1, D, gm.data_ptr(), bt.data_ptr(), 1e-5, dout.data_ptr(), 1,
-                                 dy.data_ptr(), dz.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), npix, D, st())
+                                 dy.data_ptr(), dz.data_ptr(), D, dgb[0].data_ptr(), dgb[1].data_ptr(), npix, D, st())
     bytes_b = npix * D * (16 + 2 + 2 + 4 + 2)
     tf, tb = timeit(f), timeit(b)
     Dh = D // 2
