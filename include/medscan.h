@@ -146,7 +146,8 @@ int ms_dwconv3x3_silu_bwd(const float *x, const float *w, const float *bias, con
  *   bwd: the incoming gradient is the sum of `dy_ndir` contiguous (batch,H,W,C) fp32 slabs `dy_dir_stride` elements apart
  *       (the scan's four per-direction du tensors are consumed as they are) plus `dy_extra` (same shape, or NULL);
  *       dx : fp32 or bf16 with its own pixel stride (it can be written straight into the x half of the xz gradient);
- *       scratch : (batch,H,W,C) fp32 workspace; dw (C,9) and dbias (C) are ACCUMULATED.
+ *       scratch : ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(batch, C, H, W) floats of workspace (the pre-activation
+ *       gradient + per-workgroup partial sums of dw/dbias; need not be initialised); dw (C,9) and dbias (C) are ACCUMULATED.
  */
 int ms_dwconv3x3_silu_nhwc_fwd(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
                                int batch, int C, int H, int W, int64_t x_pixel_stride, void *stream);
@@ -154,6 +155,7 @@ int ms_dwconv3x3_silu_nhwc_bwd(const void *x, int x_is_bf16, const float *w, con
                                int64_t dy_dir_stride, const float *dy_extra, void *dx, int dx_is_bf16, int64_t dx_pixel_stride,
                                float *scratch, float *dw, float *dbias, int batch, int C, int H, int W,
                                int64_t x_pixel_stride, void *stream);
+int64_t ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(int batch, int C, int H, int W);
 
 /*
  * Fused tail of SS2D (MedMamba.py:476-479): cross-merge sum of the four directions + LayerNorm(D) + SiLU gate.

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmedscan.so")
+_SO = os.environ.get("MEDSCAN_LIBRARY") or os.path.join(_HERE, "libmedscan.so")    # override: kernel-variant experiments
 _CSRC = os.path.join(_HERE, "csrc")
 
 c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
@@ -48,7 +48,7 @@ class MsScanBwdParams(ctypes.Structure):
 
 EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_cross_scan",
            "ms_cross_merge", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_dwconv3x3_silu_nhwc_fwd",
-           "ms_dwconv3x3_silu_nhwc_bwd", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
+           "ms_dwconv3x3_silu_nhwc_bwd", "ms_dwconv3x3_silu_nhwc_bwd_scratch_floats", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_bwd", "ms_bn_relu_nhwc_fwd",
            "ms_bn_relu_nhwc_bwd", "ms_bn_scratch_floats", "ms_spin", "ms_abi_version", "ms_status_string")
 ABI_VERSION = 4
@@ -92,6 +92,7 @@ def lib():
     h.ms_dwconv3x3_silu_nhwc_fwd.argtypes = [c_vp, ctypes.c_int] + [c_vp] * 3 + [ctypes.c_int] * 4 + [c_i64, c_vp]
     h.ms_dwconv3x3_silu_nhwc_bwd.argtypes = ([c_vp, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, ctypes.c_int,
                                               c_i64, c_vp, c_vp, c_vp] + [ctypes.c_int] * 4 + [c_i64, c_vp])
+    h.ms_dwconv3x3_silu_nhwc_bwd_scratch_floats.argtypes = [ctypes.c_int] * 4
     c_f, c_int = ctypes.c_float, ctypes.c_int
     h.ms_ln_gate_fwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_i64, c_int, c_vp]
     h.ms_ln_gate_bwd.argtypes = [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_f, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp,
@@ -111,6 +112,7 @@ def lib():
     h.ms_status_string.argtypes = [ctypes.c_int]
     for name in EXPORTS[:-1]:
         getattr(h, name).restype = ctypes.c_int
+    h.ms_dwconv3x3_silu_nhwc_bwd_scratch_floats.restype = c_i64
     if h.ms_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != {ABI_VERSION} (stale build?)")
     _lib = h

@@ -14,6 +14,7 @@ int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const
                         float *dw, float *dbias, int batch, int C, int H, int W, hipStream_t s);
 int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
                              int batch, int C, int H, int W, int64_t xps, hipStream_t s);
+int64_t dwconv_nhwc_bwd_scratch_floats(int batch, int C, int H, int W);
 int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int ndir,
                              int64_t dir_stride, const float *dy_extra, void *dx, int dx_bf16, int64_t dxps, float *scratch,
                              float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s);
@@ -149,6 +150,10 @@ int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, co
                         float *scratch, int64_t npix, int C, void *stream) {
     return ms::bn_bwd_dispatch(x, x_is_bf16, x_pixel_stride, dy, dy_is_bf16, gamma, beta, save_mean, save_rstd, relu, dx, dgamma, dbeta,
                                scratch, npix, C, (hipStream_t)stream);
+}
+
+int64_t ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(int batch, int C, int H, int W) {
+    return ms::dwconv_nhwc_bwd_scratch_floats(batch, C, H, W);
 }
 
 int ms_bn_scratch_floats(int C) { return ms::bn_scratch_floats(C); }

@@ -73,14 +73,23 @@ dwconv_nhwc_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w, con
 // Backward, pass 1: dpre = dy * silu'(conv(x) + b) for one image row (same sliding window as the forward: 3 loads
 // per pixel), stored to a scratch tensor; the parameter gradients dw[c, 0..8], dbias[c] are accumulated per lane over the
 // row and added with one atomic per (row, channel).
-constexpr int kRowsPerWaveBwd1 = 2;      // rows per wave in pass 1; with the 4-wave LDS combine: 8x fewer same-address atomics
+#ifndef DW_ROWS
+#define DW_ROWS 2
+#endif
+#ifndef DW_COLS
+#define DW_COLS 4
+#endif
+constexpr int kRowsPerWaveBwd1 = DW_ROWS;      // rows per wave in pass 1; with the 4-wave LDS combine: 8x fewer same-address atomics
+constexpr int kColsBwd1 = DW_COLS;      // columns per trip in pass 1
 
-template <typename T>
+// NDIR > 0: the slab count is a compile-time constant, so the 4 x (NDIR + EXTRA) gradient loads of a trip are issued
+// together with the 12 window loads (a run-time slab loop makes each add wait for its own load: measured 330 us instead
+// of ~100 us at stage 0).  NDIR == 0: run-time `ndir`, any count up to 8.
+template <typename T, int NDIR, bool EXTRA>
 __global__ void __launch_bounds__(256)
 dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                         const float *__restrict__ dy, int ndir, int64_t dir_stride, const float *__restrict__ dy_extra,
-                        float *__restrict__ dpre, float *__restrict__ dw,
-                        float *__restrict__ dbias, int C, int H, int W, int64_t xps, int rows) {
+                        float *__restrict__ dpre, float *__restrict__ part, int C, int H, int W, int64_t xps, int rows) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     __shared__ float red[3][10][64];
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -104,14 +113,15 @@ dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, co
         float a0 = 0, a1 = 0, a2 = 0, b0, b1, b2;
         b0 = v0 ? ldf(r0) : 0.0f; b1 = ldf(r1); b2 = v2 ? ldf(r2) : 0.0f;
         const float *go = dy + (int64_t)row * W * C + cc;
+        const float *ge = EXTRA ? dy_extra + (int64_t)row * W * C + cc : nullptr;
         float *po = dpre + (int64_t)row * W * C + c;
         // 4 columns per trip: the 16 loads of a trip (3 rows x 4 next columns + 4 dy) are issued together, so a wave keeps
         // 16 requests in flight instead of 4 -- the walk along the row is latency-bound otherwise (measured 245 us for a
         // 192 MB pass at stage 0)
-        for (int w0 = 0; w0 < W; w0 += 4) {
-            float n0[4], n1[4], n2[4], gq[4];
+        for (int w0 = 0; w0 < W; w0 += kColsBwd1) {
+            float n0[kColsBwd1], n1[kColsBwd1], n2[kColsBwd1], gq[kColsBwd1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kColsBwd1; ++q) {
                 const int wn = w0 + q + 1;                       // the column to the right of pixel w0 + q
                 const bool in = wn < W;
                 const int64_t o = (int64_t)(in ? wn : W - 1) * xps;
@@ -121,19 +131,33 @@ dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, co
                 // (the x_proj backward): summed here instead of by separate reduce / add kernels
                 const int64_t gi = (int64_t)min(w0 + q, W - 1) * C;
                 float gs = go[gi];
-                for (int kd = 1; kd < ndir; ++kd) gs += go[gi + kd * dir_stride];
-                if (dy_extra) gs += dy_extra[(int64_t)row * W * C + cc + gi];
+                if (NDIR > 0) {
+                    float gk[NDIR > 0 ? NDIR : 1];
+#pragma unroll
+                    for (int kd = 1; kd < NDIR; ++kd) gk[kd] = go[gi + kd * dir_stride];
+                    const float gx = EXTRA ? ge[gi] : 0.0f;
+#pragma unroll
+                    for (int kd = 1; kd < NDIR; ++kd) gs += gk[kd];
+                    gs += gx;
+                } else {
+                    for (int kd = 1; kd < ndir; ++kd) gs += go[gi + kd * dir_stride];
+                    if (EXTRA) gs += ge[gi];
+                }
                 gq[q] = gs;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kColsBwd1; ++q) {
                 if (w0 + q < W) {
                     const float c0 = n0[q], c1 = n1[q], c2 = n2[q], g = gq[q];
                     float pre = bv;
                     pre = fmaf(k[0], a0, pre); pre = fmaf(k[1], b0, pre); pre = fmaf(k[2], c0, pre);
                     pre = fmaf(k[3], a1, pre); pre = fmaf(k[4], b1, pre); pre = fmaf(k[5], c1, pre);
                     pre = fmaf(k[6], a2, pre); pre = fmaf(k[7], b2, pre); pre = fmaf(k[8], c2, pre);
+                    #ifdef DW_FASTSIG
+                    const float sg = __frcp_rn(1.0f + __expf(-pre));
+#else
                     const float sg = sigm(pre);
+#endif
                     const float dp = g * (sg * (1.0f + pre * (1.0f - sg)));
                     if (cv) po[(int64_t)(w0 + q) * C] = dp;
                     acc[0] = fmaf(dp, a0, acc[0]); acc[1] = fmaf(dp, b0, acc[1]); acc[2] = fmaf(dp, c0, acc[2]);
@@ -145,18 +169,49 @@ dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, co
             }
         }
     }
-    // combine the block's 4 waves (same channels, different rows) in LDS, then one atomic per (block, channel, tap)
+    // combine the block's 4 waves (same channels, different rows) in LDS; the block's 10 sums per channel go to its own
+    // slot of `part` ([gridDim.y][10][gridDim.x*64]) and dwconv_nhwc_bwd_finalize_kernel adds the slots up.  (Atomics on
+    // the 10*C result addresses serialise: measured 65 of 230 us at stage 0.)
     if (wv > 0) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) red[wv - 1][i][ln] = acc[i];
     }
     __syncthreads();
-    if (wv == 0 && cv) {
+    if (wv == 0) {
+        const int cpad = gridDim.x * 64;
+        float *po = part + (int64_t)blockIdx.y * 10 * cpad + blockIdx.x * 64 + ln;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i] += red[0][i][ln] + red[1][i][ln] + red[2][i][ln];
+        for (int i = 0; i < 10; ++i) po[i * cpad] = cv ? acc[i] + red[0][i][ln] + red[1][i][ln] + red[2][i][ln] : 0.0f;
+    }
+}
+
+// dw[c, 0..8] += sum over slots of part[slot][0..8][c], dbias[c] += ... [9][c].  One block = 64 columns (a column =
+// (tap, channel), contiguous in `part`) x 16 slot slices; sole writer of its outputs, so plain read-modify-write.
+__global__ void __launch_bounds__(1024)
+dwconv_nhwc_bwd_finalize_kernel(const float *__restrict__ part, int nslots, int cpad, int C, float *__restrict__ dw,
+                                float *__restrict__ dbias) {
+    __shared__ float red[16][64];
+    const int ln = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + ln;                       // < 10 * cpad (cpad is a multiple of 64)
+    const float *p = part + col;
+    const int64_t pitch = (int64_t)10 * cpad;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = sl;
+    for (; k + 48 < nslots; k += 64) {
+        s0 += p[k * pitch]; s1 += p[(k + 16) * pitch]; s2 += p[(k + 32) * pitch]; s3 += p[(k + 48) * pitch];
+    }
+    for (; k < nslots; k += 16) s0 += p[k * pitch];
+    red[sl][ln] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(dw + c * 9 + i, acc[i]);
-        if (dbias) atomicAdd(dbias + c, acc[9]);
+        for (int j = 0; j < 16; ++j) t += red[j][ln];
+        const int i = col / cpad, c = col - i * cpad;
+        if (c < C) {
+            if (i < 9) dw[c * 9 + i] += t;
+            else if (dbias) dbias[c] += t;
+        }
     }
 }
 
@@ -234,12 +289,28 @@ static int launch_bwd(const void *x, const float *w, const float *bias, const fl
     // dx doubles as the dpre scratch of pass 1?  No: pass 2 reads rows h-1..h+1 of dpre while writing row h of dx,
     // so dpre needs its own buffer -- the caller passes it in `scratch` ((batch, H, W, C) fp32).
     const int tasks = (rows + kRowsPerWaveBwd1 - 1) / kRowsPerWaveBwd1;
-    hipLaunchKernelGGL((dwconv_nhwc_bwd1_kernel<T>), dim3((C + 63) / 64, (tasks + 3) / 4, 1), dim3(256), 0, s,
-                       (const T *)x, w, bias, dy, ndir, dir_stride, dy_extra, scratch, dw, dbias, C, H, W, xps, rows);
+    const dim3 g1((C + 63) / 64, (tasks + 3) / 4, 1);
+    float *part = scratch + (int64_t)rows * W * C;            // behind dpre: dwconv_nhwc_bwd_scratch_floats()
+#define MS_BWD1(ND, EX) hipLaunchKernelGGL((dwconv_nhwc_bwd1_kernel<T, ND, EX>), g1, dim3(256), 0, s, (const T *)x, w, bias, dy, \
+                                           ndir, dir_stride, dy_extra, scratch, part, C, H, W, xps, rows)
+    if (ndir == 1 && !dy_extra) MS_BWD1(1, false);
+    else if (ndir == 4 && dy_extra) MS_BWD1(4, true);
+    else if (dy_extra) MS_BWD1(0, true);
+    else MS_BWD1(0, false);
+#undef MS_BWD1
+    const int cpad = (int)g1.x * 64;
+    hipLaunchKernelGGL(dwconv_nhwc_bwd_finalize_kernel, dim3(10 * cpad / 64), dim3(1024), 0, s, part, (int)g1.y, cpad, C, dw, dbias);
     const dim3 g2((C + 63) / 64, (rows + 3) / 4, 1);
     if (dx_bf16) hipLaunchKernelGGL((dwconv_nhwc_bwd2_kernel<unsigned short>), g2, dim3(256), 0, s, scratch, w, (unsigned short *)dx, dxps, C, H, W, rows);
     else         hipLaunchKernelGGL((dwconv_nhwc_bwd2_kernel<float>), g2, dim3(256), 0, s, scratch, w, (float *)dx, dxps, C, H, W, rows);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int64_t dwconv_nhwc_bwd_scratch_floats(int batch, int C, int H, int W) {
+    if (batch < 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t rows = (int64_t)batch * H;
+    const int64_t tasks = (rows + kRowsPerWaveBwd1 - 1) / kRowsPerWaveBwd1;
+    return rows * W * C + ((tasks + 3) / 4) * 10 * (((int64_t)C + 63) / 64 * 64);
 }
 
 int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int ndir,

@@ -50,7 +50,7 @@ class _DWConvSiLUNHWC(torch.autograd.Function):
         B, H, W, C = x.shape
         dy = dy.contiguous().float()
         dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
-        scratch = torch.empty_like(dx)
+        scratch = _dwconv_bwd_scratch(B, C, H, W, x.device)
         dw = torch.zeros_like(w)
         db = torch.zeros_like(b) if b is not None else None
         with _lib.on_device(x.device):
@@ -60,6 +60,11 @@ class _DWConvSiLUNHWC(torch.autograd.Function):
                 db.data_ptr() if db is not None else None, B, C, H, W, ctx.ps, _lib.current_stream_ptr(x.device)),
                 "ms_dwconv3x3_silu_nhwc_bwd")
         return dx.to(x.dtype), dw.to(ctx.wdtype), (db.to(ctx.bdtype) if db is not None else None)
+
+
+def _dwconv_bwd_scratch(B, C, H, W, device):
+    """Workspace of ms_dwconv3x3_silu_nhwc_bwd: the pre-activation gradient + the per-workgroup dw/dbias partial sums."""
+    return torch.empty(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(B, C, H, W), device=device, dtype=torch.float32)
 
 
 def dwconv3x3_silu_nhwc(x, weight, bias):
@@ -349,7 +354,7 @@ class _SS2DInner(torch.autograd.Function):
         du4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
         ddelta = torch.empty_like(du4)
         dproj = torch.zeros_like(proj)
-        scratch = torch.empty_like(xc)
+        scratch = _dwconv_bwd_scratch(B, D, H, W, dev)
         sizes = (A.numel(), Dv.numel(), bias.numel(), gamma.numel(), beta.numel(), cw.numel(), cb.numel() if cb is not None else 0)
         zbuf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
         dA, dD, dbias, dgamma, dbeta, dcw, dcb = zbuf.split(sizes)

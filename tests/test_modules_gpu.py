@@ -281,7 +281,7 @@ def test_dwconv_nhwc_bwd_sums_direction_slabs_and_writes_strided_dx(bf16):
     d = dev(); dt = torch.bfloat16 if bf16 else torch.float32
     xzd, wd, bd, g4d, ged = xz.to(d, dt), w.to(d).contiguous(), b.to(d), g4.to(d), ge.to(d)
     dxz = torch.full((B, H, W, 2 * C), 7.0, device=d, dtype=dt)
-    scratch = torch.empty(B, H, W, C, device=d); dw = torch.zeros(C, 9, device=d); db = torch.zeros(C, device=d)
+    scratch = torch.empty(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(B, C, H, W), device=d); dw = torch.zeros(C, 9, device=d); db = torch.zeros(C, device=d)
     _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd(
         xzd.data_ptr(), int(bf16), wd.data_ptr(), bd.data_ptr(), g4d.data_ptr(), 4, B * H * W * C, ged.data_ptr(),
         dxz.data_ptr(), int(bf16), 2 * C, scratch.data_ptr(), dw.data_ptr(), db.data_ptr(), B, C, H, W, 2 * C,
