@@ -140,12 +140,12 @@ def ssd_scan_merge(mod, xc):
     B, H, W, conv_dim = xc.shape
     L, K = H * W, 4
     GN = mod.ngroups * mod.d_state
-    if SSD_PIXEL_ORDER and mod.ngroups == 1 and mod.d_state <= 16 and H * W < (1 << 22):
+    if SSD_PIXEL_ORDER and mod.ngroups == 1 and H * W < (1 << 22):
         # native path: the scan kernels take the four pixel orders themselves, one launch per direction's B/C slice
         from .ss2d_fused import ssd_scan_merge_pixel
         return ssd_scan_merge_pixel(xc, -torch.exp(mod.A_logs.float()), mod.Ds, mod.dt_bias.view(-1), mod.d_ssm, mod.d_state,
                                     mod.nheads, mod.headdim, mod.D_has_hdim)
-    # general path (ngroups > 1 or d_state > 16): 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
+    # general path (ngroups > 1): 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
     idx, inv = _scan_orders(H, W, xc.device)
     xs4 = xc.reshape(B, L, conv_dim)[:, idx.reshape(-1)].view(B, K, L, conv_dim).transpose(1, 2)
     xs, Bs, Cs, dts = torch.split(xs4, [mod.d_ssm, GN, GN, mod.nheads], dim=-1)

@@ -457,8 +457,8 @@ class _SSDScanMerge(torch.autograd.Function):
     """4-direction SSD scan of SS2D_with_SSD / CrossMamba (CNN_Mamba.py:494-552) on the conv output in PIXEL order -- no
     gathered copies of the four scan orders and no inverse gathers: `xc` (B,H,W,conv_dim) = [x (Ds) | B (N) | C (N) | dt
     (nheads)] per pixel, ngroups == 1.  Heads = (direction, head); every head's state is the concatenation of the four
-    directions' B/C (CNN_Mamba.py:506-519), so the state axis is covered by four launches: launch j takes B/C through
-    direction j's pixel order for ALL groups (MS_SCAN_BC_MAP) while u / dt / y follow each group's own direction, and
+    directions' B/C (CNN_Mamba.py:506-519), so the state axis is covered by 4 * ceil(N/16) launches: launch (j, slice) takes
+    16 states of B/C through direction j's pixel order for ALL groups (MS_SCAN_BC_MAP) while u / dt / y follow each group's own direction, and
     adds into the same y (MS_SCAN_ACCUMULATE).  Scalar decay per head (A stride 0 over states)."""
 
     @staticmethod
@@ -476,13 +476,15 @@ class _SSDScanMerge(torch.autograd.Function):
         delta = xc[..., Ds + 2 * N:].repeat_interleave(headdim, dim=-1).view(B, L, Ds)      # dt of a pixel, per channel
         y4 = torch.empty((4, B, L, Ds), device=xc.device, dtype=torch.float32)
         n_chunks = lib.ms_scan_n_chunks(L)
-        x_state = torch.empty((4, B, n_chunks, N, 4 * Ds), device=xc.device, dtype=torch.float32)
+        slices = _ssd_slices(N)                          # (direction j, first state, states) per launch
+        x_state = torch.empty((len(slices), B, n_chunks, _SSD_SLICE, 4 * Ds), device=xc.device, dtype=torch.float32)
         stream = _lib.current_stream_ptr(xc.device)
         with _lib.on_device(xc.device):
-            for j in range(4):
+            for i, (j, s0, ns) in enumerate(slices):
                 P = MsScanParams()
-                _ssd_params(P, xc, delta, A_col, D_full if j == 0 else None, bias_full, y4, x_state[j], B, L, H, W, Ds, N, conv, j)
-                rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * Ds, L, N, 4, False), xc.device,
+                _ssd_params(P, xc, delta, A_col, D_full if i == 0 else None, bias_full, y4, x_state[i], B, L, H, W, Ds, N, conv,
+                            j, s0, ns, i > 0)
+                rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * Ds, L, ns, 4, False), xc.device,
                                   lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
                 _lib.check(rc, "ms_selective_scan_fwd[ssd]")
         ctx.save_for_backward(xc, delta, A_col, D_full, bias_full, x_state)
@@ -499,38 +501,50 @@ class _SSDScanMerge(torch.autograd.Function):
         du4 = torch.empty((4, B, L, Ds), device=xc.device, dtype=torch.float32)
         dd4 = torch.empty_like(du4)
         dxc = torch.zeros_like(xc)                       # the B|C columns are accumulated by the kernels (atomics)
-        sizes = (4 * Ds * N, 4 * Ds, 4 * Ds)
+        # dA comes back dense, (channel, state of the launch): one accumulator per distinct slice width
+        widths = sorted({ns for _, _, ns in _ssd_slices(N)})
+        sizes = tuple(4 * Ds * w for w in widths) + (4 * Ds, 4 * Ds)
         zbuf = torch.zeros(sum(sizes), device=xc.device, dtype=torch.float32)
-        dA, dD, dbias = zbuf.split(sizes)
+        *dA_w, dD, dbias = zbuf.split(sizes)
+        dA_of = dict(zip(widths, dA_w))
         stream = _lib.current_stream_ptr(xc.device)
         with _lib.on_device(xc.device):
-            for j in range(4):
+            for i, (j, s0, ns) in enumerate(_ssd_slices(N)):
                 Q = MsScanBwdParams()
-                _ssd_params(Q.f, xc, delta, A_col, D_full if j == 0 else None, bias_full, None, x_state[j], B, L, H, W, Ds, N, conv, j)
+                _ssd_params(Q.f, xc, delta, A_col, D_full if i == 0 else None, bias_full, None, x_state[i], B, L, H, W, Ds, N, conv,
+                            j, s0, ns, i > 0)
                 Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * Ds, 0, 1, Ds
                 Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * Ds, B * L * Ds, 1, Ds
                 Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * Ds, B * L * Ds, 1, Ds
                 Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = L * conv, 0, 1, conv
                 Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = L * conv, 0, 1, conv
                 Q.dout, Q.du, Q.ddelta = dy.data_ptr(), du4.data_ptr(), dd4.data_ptr()
-                Q.dA, Q.ddelta_bias = dA.data_ptr(), dbias.data_ptr()
-                Q.dD = dD.data_ptr() if j == 0 else None
-                Q.dB, Q.dC = dxc.data_ptr() + 4 * Ds, dxc.data_ptr() + 4 * (Ds + N)
-                rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * Ds, L, N, 4, True), xc.device,
+                Q.dA, Q.ddelta_bias = dA_of[ns].data_ptr(), dbias.data_ptr()
+                Q.dD = dD.data_ptr() if i == 0 else None
+                Q.dB, Q.dC = dxc.data_ptr() + 4 * (Ds + s0), dxc.data_ptr() + 4 * (Ds + N + s0)
+                rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * Ds, L, ns, 4, True), xc.device,
                                   lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream))
                 _lib.check(rc, "ms_selective_scan_bwd[ssd]")
         dxc[..., :Ds] = du4.sum(dim=0).view(B, H, W, Ds)
         dxc[..., Ds + 2 * N:] = dd4.sum(dim=0).view(B, H, W, nheads, headdim).sum(dim=-1)
-        dAs = dA.view(4 * nheads, headdim * N).sum(dim=1).view(a_shape)
+        dAs = sum(dA_of[w].view(4 * nheads, headdim * w).sum(dim=1) for w in widths).view(a_shape)
         dDs = dD.view(d_shape) if d_has_hdim else dD.view(4 * nheads, headdim).sum(dim=1).view(d_shape)
         dbt = dbias.view(4 * nheads, headdim).sum(dim=1).view(b_shape)
         return dxc, dAs, dDs, dbt, None, None, None, None, None, None, None
 
 
-def _ssd_params(P, xc, delta, A_col, D_full, bias_full, y4, x_state, B, L, H, W, Ds, N, conv, j):
-    """Slice j of the SSD state axis: B/C through direction j's pixel order (see _SSDScanMerge)."""
-    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = B, 4 * Ds, L, N, 4
-    P.delta_softplus = 1 | ((j + 1) << 4) | (4 if j > 0 else 0)        # SOFTPLUS | BC_MAP(j) | ACCUMULATE
+_SSD_SLICE = 16      # states per launch (the scan kernels keep <= 16 states of a channel in registers)
+
+
+def _ssd_slices(N):
+    return [(j, s0, min(_SSD_SLICE, N - s0)) for j in range(4) for s0 in range(0, N, _SSD_SLICE)]
+
+
+def _ssd_params(P, xc, delta, A_col, D_full, bias_full, y4, x_state, B, L, H, W, Ds, N, conv, j, s0, ns, accumulate):
+    """One slice of the SSD state axis: states s0..s0+ns of direction j's B/C, read through direction j's pixel order
+    (see _SSDScanMerge)."""
+    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = B, 4 * Ds, L, ns, 4
+    P.delta_softplus = 1 | ((j + 1) << 4) | (4 if accumulate else 0)   # SOFTPLUS | BC_MAP(j) | ACCUMULATE
     P.map_h, P.map_w = H, W
     P.u_batch_stride, P.u_group_stride, P.u_d_stride, P.u_l_stride = L * conv, 0, 1, conv
     P.delta_batch_stride, P.delta_group_stride, P.delta_d_stride, P.delta_l_stride = L * Ds, 0, 1, Ds
@@ -539,7 +553,7 @@ def _ssd_params(P, xc, delta, A_col, D_full, bias_full, y4, x_state, B, L, H, W,
     P.B_batch_stride, P.B_group_stride, P.B_dstate_stride, P.B_l_stride = L * conv, 0, 1, conv
     P.C_batch_stride, P.C_group_stride, P.C_dstate_stride, P.C_l_stride = L * conv, 0, 1, conv
     P.u, P.delta, P.A = xc.data_ptr(), delta.data_ptr(), A_col.data_ptr()
-    P.B, P.C = xc.data_ptr() + 4 * Ds, xc.data_ptr() + 4 * (Ds + N)
+    P.B, P.C = xc.data_ptr() + 4 * (Ds + s0), xc.data_ptr() + 4 * (Ds + N + s0)
     P.D = D_full.data_ptr() if D_full is not None else None
     P.delta_bias = bias_full.data_ptr()
     P.out = y4.data_ptr() if y4 is not None else None
@@ -547,7 +561,7 @@ def _ssd_params(P, xc, delta, A_col, D_full, bias_full, y4, x_state, B, L, H, W,
 
 
 def ssd_scan_merge_pixel(xc, As, Dsv, dt_bias, d_ssm, d_state, nheads, headdim, d_has_hdim):
-    """(B,H,W,conv_dim) fp32 -> (B,H,W,d_ssm) fp32: the four directions scanned and merged, for ngroups == 1, d_state <= 16."""
+    """(B,H,W,conv_dim) fp32 -> (B,H,W,d_ssm) fp32: the four directions scanned and merged, for ngroups == 1."""
     B, H, W, _ = xc.shape
     with torch.autocast(device_type="cuda", enabled=False):
         y = _SSDScanMerge.apply(xc.float(), As, Dsv, dt_bias, H, W, d_ssm, d_state, nheads, headdim, d_has_hdim)

@@ -133,10 +133,20 @@ def crossmamba_forward_oracle(mod, u1, u2, u2_cat_u1, u1_cat_u2):
 
 
 def install_ssd(model):
-    """Rebind every SS2D_with_SSD in `model` to the CPU restatement (CPU-side checker of the GPU modules)."""
+    """Rebind every SS2D_with_SSD and CrossMamba in `model` to the CPU restatement (CPU-side checker of the GPU modules)."""
     import types
     from medical_image_classification_amd.cnn_mamba import SS2D_with_SSD
+    from medical_image_classification_amd.crossmamba import CrossMamba
     for m in model.modules():
         if isinstance(m, SS2D_with_SSD):
             m.forward = types.MethodType(lambda self, u, **kw: ss2d_ssd_forward_oracle(self, u), m)
+        elif isinstance(m, CrossMamba):
+            m.forward = types.MethodType(lambda self, u1, u2, c21, c12, **kw: crossmamba_forward_oracle(self, u1, u2, c21, c12), m)
     return model
+
+
+def vfefm_forward_oracle(model, x1, x2):
+    """VFEFM.forward (CrossMamba_fusion_2b2.py:1276-1285) on CPU for a model prepared by install_ssd: the product's forward
+    refuses CPU tensors, its stage methods are plain torch once the SSD modules are rebound."""
+    f1, f2, skip = model.forward_down(x1.permute(0, 2, 3, 1), x2.permute(0, 2, 3, 1))
+    return model.final_conv(model.forward_up(f1, f2, skip).permute(0, 3, 1, 2))

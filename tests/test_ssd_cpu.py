@@ -187,3 +187,68 @@ def test_checkpoint_formats_round_trip(tmp_path):
         assert torch.equal(a, b), k
     # a DDP-wrapped save carries the "module." prefix (ddp_train.py:188 saves model.module: no prefix) -- strip works
     fresh.load_state_dict({k.removeprefix("module."): v for k, v in {"module." + k: v for k, v in ck["model"].items()}.items()})
+
+
+def test_vfefm_state_dict_surface_and_cpu_oracle_runs():
+    """VFEFM (CrossMamba_fusion_2b2.py:1078-1285) as CrossMamba/train.py:80-91 builds it: parameter names / shapes read off
+    the reference constructor, the decoder's channel plan, and a CPU pass of a small instance through the oracle modules.
+    PARITY UNPINNED against the reference itself (its SSD dependency is absent)."""
+    from medical_image_classification_amd.crossmamba import VFEFM
+    from oracle import ssd_oracle
+    torch.manual_seed(0)
+    m = VFEFM(in_chans=3, patch_size=4, depths=[2, 2, 4, 2], dims=[128, 256, 512, 1024], depths_decoder=[2, 9, 2, 2],
+              dims_decoder=[1024, 512, 256, 128], cat_method="stack", attn_drop_rate=0.0, drop_path_rate=0.1)
+    sd = m.state_dict()
+    shp = lambda k: tuple(sd[k].shape)
+    assert shp("patch_embed1.proj.weight") == (128, 3, 4, 4) and shp("patch_embed2.norm.weight") == (128,)
+    assert shp("norm.weight") == (256,) and shp("final_cat_proj.weight") == (128, 256)
+    assert shp("final_expand.expand.weight") == (512, 128) and shp("final_expand.norm.weight") == (32,)
+    assert shp("final_conv.weight") == (1, 32, 1, 1)
+    assert shp("bridge1.weight") == (1024, 1024, 1, 1) and shp("bridge2.bias") == (1024,)
+    # encoder stage 0: dim 128 -> blocks on halves of 64 channels, MedSSD(d_model=64, d_state=128): 2 heads of 64
+    assert shp("layers.0.blocks1.0.ln_1.weight") == (64,)
+    assert shp("layers.0.blocks1.0.self_attention.in_proj.weight") == (2 * 128 + 2 * 128 + 2, 64)
+    assert shp("layers.0.blocks2.1.self_attention.conv2d.weight") == (128 + 256 + 2, 1, 3, 3)
+    assert shp("layers.0.blocks1.0.self_attention.dt_bias") == (4, 2) and shp("layers.0.blocks1.0.self_attention.A_logs") == (8,)
+    assert shp("layers.0.cat_proj.weight") == (128, 256)
+    assert shp("layers.0.fusion.skip_in_proj.weight") == (256, 128) and shp("layers.0.fusion.BCdts_in_proj.weight") == (260, 128)
+    assert shp("layers.0.downsample1.reduction.weight") == (256, 512)
+    assert "layers.3.downsample1.reduction.weight" not in sd
+    # decoder: block dims 512, 256, 128, 128; the last stage has no upsample, the first no skip (but still owns in_proj1/2)
+    for i, d in enumerate((512, 256, 128, 128)):
+        assert shp(f"layers_up.{i}.in_proj1.weight") == (d, 2 * d) and shp(f"layers_up.{i}.cat_proj.weight") == (d, 2 * d)
+        assert shp(f"layers_up.{i}.blocks1.0.ln_1.weight") == (d // 2,)
+    assert shp("layers_up.0.upsample1.expand.weight") == (2048, 1024) and shp("layers_up.0.upsample1.norm.weight") == (512,)
+    assert "layers_up.3.upsample1.expand.weight" not in sd
+    assert len([k for k in sd if k.startswith("layers_up.1.blocks1.")]) == 9 * len([k for k in sd if k.startswith("layers_up.1.blocks1.0.")])
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
+    small = VFEFM(depths=[1, 1, 1, 1], dims=[64, 128, 256, 512], depths_decoder=[1, 1, 1, 1], dims_decoder=[512, 256, 128, 64],
+                  d_state=4, drop_path_rate=0.0)
+    ssd_oracle.install_ssd(small)
+    out = ssd_oracle.vfefm_forward_oracle(small, torch.randn(1, 3, 64, 64), torch.randn(1, 3, 64, 64))
+    assert tuple(out.shape) == (1, 1, 64, 64) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fusion_loss_matches_reference_vectors(tag):
+    """fusion_loss.FusionLoss / ms_ssim against vectors produced by running the reference's loss.py on CPU
+    (tools/make_golden_fusion.py -> tests/golden/fusion_loss.npz): every returned term and d(total)/d(fused image)."""
+    import os
+    from medical_image_classification_amd.fusion_loss import FusionLoss, ms_ssim
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fusion_loss.npz"))
+    vis, ir = torch.from_numpy(g[f"{tag}_vis"]), torch.from_numpy(g[f"{tag}_ir"])
+    gen = torch.from_numpy(g[f"{tag}_gen"]).requires_grad_()
+    total, loss_in, ssim_value, loss_grad = FusionLoss()(vis, ir, gen)
+    total.backward()
+    for name, v in (("total", total), ("loss_in", loss_in), ("ssim_value", ssim_value), ("loss_grad", loss_grad)):
+        np.testing.assert_allclose(v.detach().numpy(), g[f"{tag}_{name}"], rtol=2e-5, atol=1e-6, err_msg=name)
+    np.testing.assert_allclose(ms_ssim(gen.detach().clamp(0, 1), vis[:, :1]).numpy(), g[f"{tag}_msssim_gen_vis"], rtol=2e-5)
+    ref = g[f"{tag}_dgen"]
+    np.testing.assert_allclose(gen.grad.numpy(), ref, rtol=1e-3, atol=1e-5 * float(np.abs(ref).max()))
+
+
+def test_fusion_lr_schedule():
+    """CrossMamba/train.py:115: lr for epoch 0 and 1 is the base rate, then x0.75 per epoch."""
+    from medical_image_classification_amd.train_fusion import epoch_lr
+    assert [round(epoch_lr(2e-4, e) / 2e-4, 6) for e in range(4)] == [1.0, 1.0, 0.75, 0.5625]
