@@ -14,17 +14,25 @@ import torch.nn.functional as F
 _MS_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
 
 
-def _gauss_window(size, channels, device, dtype, sigma=1.5):
-    g = torch.tensor([math.exp(-((i - size // 2) ** 2) / (2.0 * sigma * sigma)) for i in range(size)])
-    g = g / g.sum()
-    return torch.outer(g, g).to(device=device, dtype=dtype).expand(channels, 1, size, size).contiguous()
+def _gauss_band(size, n, device, dtype, sigma=1.5):
+    """(n - size + 1, n) banded matrix whose rows hold the normalised 1-D Gaussian of loss.py:16-18: the reference's 2-D
+    window is the outer product of that vector with itself (loss.py:22-26), so its valid (unpadded) depthwise conv2d equals
+    G_H @ x @ G_W^T exactly.  Written as two GEMMs on purpose: the single-channel 11x11 convolutions of the 5-level chain
+    take MIOpen down with a memory access fault in backward at 224x224 (ROCm 7.2, MI355X, seen in this repo's round 1)."""
+    g = torch.tensor([math.exp(-((i - size // 2) ** 2) / (2.0 * sigma * sigma)) for i in range(size)], dtype=torch.float64)
+    g = (g / g.sum()).to(dtype)
+    m = torch.zeros(n - size + 1, n, dtype=dtype)
+    for r in range(n - size + 1):
+        m[r, r:r + size] = g
+    return m.to(device)
 
 
 def _ssim_and_cs(a, b, window_size=11):
     """Mean SSIM and mean contrast-structure term of two (B,C,H,W) images in [0,1] (loss.py:32-80, no padding)."""
-    C, H, W = a.shape[1:]
-    win = _gauss_window(min(window_size, H, W), C, a.device, a.dtype)
-    blur = lambda t: F.conv2d(t, win, groups=C)
+    H, W = a.shape[2:]
+    k = min(window_size, H, W)
+    gh, gw = _gauss_band(k, H, a.device, a.dtype), _gauss_band(k, W, a.device, a.dtype).t()
+    blur = lambda t: torch.matmul(torch.matmul(gh, t), gw)
     mu_a, mu_b = blur(a), blur(b)
     var_a, var_b, cov = blur(a * a) - mu_a * mu_a, blur(b * b) - mu_b * mu_b, blur(a * b) - mu_a * mu_b
     c1, c2 = 0.01 ** 2, 0.03 ** 2
@@ -51,12 +59,16 @@ def ms_ssim(a, b, window_size=11, normalize=True):
 class FusionLoss(nn.Module):
     def __init__(self):
         super().__init__()
-        kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]])
-        self.register_buffer("kx", kx.view(1, 1, 3, 3), persistent=False)
-        self.register_buffer("ky", (-kx.t()).contiguous().view(1, 1, 3, 3), persistent=False)
 
-    def _sobel(self, x):
-        return F.conv2d(x, self.kx, padding=1).abs() + F.conv2d(x, self.ky, padding=1).abs()
+    @staticmethod
+    def _sobel(x):
+        """|x (*) kx| + |x (*) ky| with zero padding 1 (loss.py:143-160), kx = [[-1,0,1],[-2,0,2],[-1,0,1]], ky = [[1,2,1],[0,0,0],
+        [-1,-2,-1]], as shifted differences."""
+        p = F.pad(x, (1, 1, 1, 1))
+        t, m, b = p[..., :-2, :], p[..., 1:-1, :], p[..., 2:, :]
+        gx = (t[..., 2:] - t[..., :-2]) + 2.0 * (m[..., 2:] - m[..., :-2]) + (b[..., 2:] - b[..., :-2])
+        gy = (t[..., :-2] + 2.0 * t[..., 1:-1] + t[..., 2:]) - (b[..., :-2] + 2.0 * b[..., 1:-1] + b[..., 2:])
+        return gx.abs() + gy.abs()
 
     def forward(self, image_vis, image_ir, generate_img):
         """-> (total, loss_in, ssim_value, loss_grad), the tuple the reference loop logs (train.py:131-152)."""

@@ -245,7 +245,7 @@ def test_fusion_loss_matches_reference_vectors(tag):
         np.testing.assert_allclose(v.detach().numpy(), g[f"{tag}_{name}"], rtol=2e-5, atol=1e-6, err_msg=name)
     np.testing.assert_allclose(ms_ssim(gen.detach().clamp(0, 1), vis[:, :1]).numpy(), g[f"{tag}_msssim_gen_vis"], rtol=2e-5)
     ref = g[f"{tag}_dgen"]
-    np.testing.assert_allclose(gen.grad.numpy(), ref, rtol=1e-3, atol=1e-5 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(gen.grad.numpy(), ref, rtol=1e-3, atol=1e-4 * float(np.abs(ref).max()))   # separable blur: fp32 rounding
 
 
 def test_fusion_lr_schedule():

@@ -1,0 +1,49 @@
+"""one fusion training step (fwd + bwd + Adam) of VFEFM as CrossMamba/train.py:80-91 builds it, on
+synthetic image pairs.  Prints one JSON line (image pairs/s, ms/step, peak memory, scan-kernel share).
+
+    python tools/bench_fusion.py --batch-size 32 --res 224 --steps 5 --warmup 2
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from medical_image_classification_amd import selective_scan_interface as ssi
+from medical_image_classification_amd.fusion_loss import FusionLoss
+from medical_image_classification_amd.train import make_adam
+from medical_image_classification_amd.train_fusion import build_fusion_model, fusion_step, synthetic_pair
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch-size", type=int, default=32)
+ap.add_argument("--res", type=int, default=224)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--d-state", type=int, default=128)
+ap.add_argument("--fp32", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = build_fusion_model(d_state=a.d_state).to(dev).train()
+opt = make_adam(net.parameters(), lr=2e-4)
+crit = FusionLoss().to(dev)
+vis, ir = synthetic_pair(a.batch_size, a.res, dev)
+ac = None if a.fp32 else torch.bfloat16
+t0 = time.perf_counter()
+for i in range(a.warmup):
+    fusion_step(net, opt, crit, vis, ir, ac); torch.cuda.synchronize()
+    print(f"[bench_fusion +{time.perf_counter() - t0:.1f}s] warm-up step {i} done, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB",
+          file=sys.stderr, flush=True)
+ssi.TIMER.enabled = True
+torch.cuda.synchronize(); t1 = time.perf_counter()
+for _ in range(a.steps):
+    terms = fusion_step(net, opt, crit, vis, ir, ac)
+torch.cuda.synchronize(); dt = time.perf_counter() - t1
+ssi.TIMER.enabled = False
+kern = ssi.TIMER.summary()
+print(json.dumps({
+    "metric": f"image pairs/sec VFEFM 2x3x{a.res}x{a.res} bs={a.batch_size} fusion train step", "value": round(a.batch_size * a.steps / dt, 2),
+    "unit": "pairs/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 1),
+    "dtype": "f32" if a.fp32 else "bf16+f32scan", "data": "synthetic",
+    "config": {"workload": f"VFEFM (CrossMamba/train.py:80-91: dims 128..1024, decoder depths 2/9/2/2, d_state {a.d_state}) fwd+bwd+Adam",
+               "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 1), "loss": round(float(terms[0]), 4)},
+    "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+    "scan": {n: {"ms_per_step": round(v["ms"] / a.steps, 1), "launches_per_step": v["launches"] // a.steps,
+                 "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for n, v in kern.items()}}), flush=True)
