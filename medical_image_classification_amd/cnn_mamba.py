@@ -38,6 +38,95 @@ SSD_PIXEL_ORDER = os.environ.get("MEDSCAN_SSD_PIXEL", "1") == "1"     # ssd_scan
 _STATE_SLICE = 16      # states per kernel call (the backward kernels are built for dstate <= 16)
 
 
+# SSD as chunked matrix products (the "state space duality" form of Mamba-2, which the reference's dependency implements in
+# Triton): one launch set for ALL states instead of one scan launch per 16 states.  Used when the state is wide enough
+# for the GEMMs to win (measured: VFEFM's 512-state heads 2.15 s -> see DESIGN.md section 9); 0 = always the scan kernels.
+SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "64"))
+_SSD_CHUNK = 64
+
+
+def _ssd_chunked(x, dt, A, B, C, D, dt_bias, dt_softplus, Q=_SSD_CHUNK):
+    """h_t = exp(dt_t A) h_{t-1} + dt_t B_t (x) x_t,  y_t = C_t . h_t + D x_t, evaluated chunk-wise:
+    inside a chunk   Y = ((C B^T) o L) X'          L[i,j] = exp(sum_{j<k<=i} dt_k A), i >= j   (X' = dt * x)
+    chunk states     S_c = sum_j exp(sum_{k>j} dt_k A) B_j^T X'_j ;  carried across chunks by their total decays
+    state -> output  Y += exp(sum_{k<=i} dt_k A) C_i S_{c-1}
+    x (b,l,h,p), dt (b,l,h), A (h), B/C (b,l,g,n) -> (b,l,h,p) fp32.  All products are batched GEMMs (hipBLASLt) in fp32;
+    autograd differentiates them."""
+    b, l, h, p = x.shape
+    g, n = B.shape[2], B.shape[3]
+    hg = h // g
+    dt = dt.float()
+    if dt_bias is not None:
+        dt = dt + dt_bias.float()
+    if dt_softplus:
+        dt = F.softplus(dt)
+    x = x.float()
+    nc = (l + Q - 1) // Q
+    pad = nc * Q - l
+    a = dt * A.float()                                             # (b,l,h) log-decay per step, <= 0
+    xd = x * dt.unsqueeze(-1)
+    Bf, Cf = B.float(), C.float()
+    if pad:                                                         # dt = 0 steps: decay 1, no input; their outputs are dropped
+        a, xd, Bf, Cf = (F.pad(t, (0, 0) * (t.dim() - 2) + (0, pad)) for t in (a, xd, Bf, Cf))
+    a = a.reshape(b, nc, Q, h).permute(0, 1, 3, 2)                  # (b,c,h,Q)
+    cum = torch.cumsum(a, dim=-1)
+    xd = xd.reshape(b, nc, Q, g, hg * p)
+    Bc = Bf.reshape(b, nc, Q, g, n).permute(0, 1, 3, 2, 4)          # (b,c,g,Q,n)
+    Cc = Cf.reshape(b, nc, Q, g, n).permute(0, 1, 3, 2, 4)
+    # inside the chunk
+    seg = cum.unsqueeze(-1) - cum.unsqueeze(-2)                     # (b,c,h,Q,Q): sum_{j<k<=i}
+    tri = torch.ones(Q, Q, device=x.device, dtype=torch.bool).tril()
+    Lm = torch.exp(seg.masked_fill(~tri, float("-inf")))
+    CB = torch.matmul(Cc, Bc.transpose(-1, -2))                     # (b,c,g,Q,Q)
+    M = Lm.view(b, nc, g, hg, Q, Q) * CB.unsqueeze(3)
+    Xh = xd.view(b, nc, Q, g, hg, p).permute(0, 1, 3, 4, 2, 5)      # (b,c,g,hg,Q,p)
+    y = torch.matmul(M, Xh)                                         # (b,c,g,hg,Q,p)
+    # chunk states (per head: n x p), the decay of input j up to the chunk's end
+    dec_in = torch.exp(cum[..., -1:] - cum)                         # (b,c,h,Q)
+    Xs = (Xh * dec_in.view(b, nc, g, hg, Q, 1)).permute(0, 1, 2, 4, 3, 5).reshape(b, nc, g, Q, hg * p)
+    S = torch.matmul(Bc.transpose(-1, -2), Xs)                      # (b,c,g,n,hg*p)
+    # carry across chunks: S_in[c] = sum_{c' < c} exp(sum_{c' < k < c} tot_k) S[c'],  tot = the chunks' total log-decays
+    tot = F.pad(cum[..., -1], (0, 0, 1, 0)).permute(0, 2, 1)       # (b,h,1+c): a leading zero for the (zero) initial state
+    ct = torch.cumsum(tot, dim=-1)
+    segc = ct.unsqueeze(-1) - ct.unsqueeze(-2)                      # (b,h,1+c,1+c)
+    tric = torch.ones(nc + 1, nc + 1, device=x.device, dtype=torch.bool).tril()
+    # Dc[b,h,z,c'] = exp(ct[z] - ct[c'+1]) for c' < z: what is left of chunk c''s end state when chunk z starts; 0 otherwise
+    Dc = torch.exp(segc.masked_fill(~tric, float("-inf")))[:, :, :-1, 1:]
+    Sh = S.view(b, nc, g, n, hg, p).permute(0, 2, 4, 1, 3, 5).reshape(b, h, nc, n * p)      # (b,h,c,n*p)
+    S_in = torch.matmul(Dc, Sh).view(b, g, hg, nc, n, p)            # (b,g,hg,z,n,p)
+    S_in = S_in.permute(0, 3, 1, 4, 2, 5).reshape(b, nc, g, n, hg * p)
+    y_off = torch.matmul(Cc, S_in).view(b, nc, g, Q, hg, p).permute(0, 1, 2, 4, 3, 5)      # (b,c,g,hg,Q,p)
+    y = y + y_off * torch.exp(cum).view(b, nc, g, hg, Q, 1)
+    y = y.permute(0, 1, 4, 2, 3, 5).reshape(b, nc * Q, h, p)[:, :l]
+    if D is not None:
+        Df = D.float()
+        y = y + x * (Df.view(h, p) if Df.dim() == 2 else Df.view(h, 1))
+    return y
+
+
+class _SSDChunked(torch.autograd.Function):
+    """_ssd_chunked with its intermediates recomputed in backward: the per-chunk states are (n x h*p) per (batch, chunk) --
+    1.6 GB per tensor for one stage-0 block of VFEFM at batch 32 -- so only the operands are kept (one extra forward per scan
+    in backward; measured on VFEFM bs 32: peak 250 -> see DESIGN.md section 9)."""
+
+    @staticmethod
+    def forward(ctx, x, dt, A, B, C, D, dt_bias, dt_softplus):
+        ctx.save_for_backward(x, dt, A, B, C, D, dt_bias)
+        ctx.dt_softplus = dt_softplus
+        with torch.no_grad():
+            return _ssd_chunked(x, dt, A, B, C, D, dt_bias, dt_softplus)
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        ins = [t.detach().requires_grad_(ctx.needs_input_grad[i]) if t is not None else None for i, t in enumerate(saved)]
+        with torch.enable_grad():
+            y = _ssd_chunked(*ins, ctx.dt_softplus)
+        wanted = [t for t in ins if t is not None and t.requires_grad]
+        grads = iter(torch.autograd.grad(y, wanted, dy))
+        return tuple(next(grads) if (t is not None and t.requires_grad) else None for t in ins) + (None,)
+
+
 def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt_bias=None, initial_states=None,
                               seq_idx=None, cu_seqlens=None, dt_softplus=False, dt_limit=(0.0, float("inf")),
                               return_final_states=False):
@@ -54,6 +143,9 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt
     g, n = B.shape[2], B.shape[3]
     if h % g != 0:
         raise RuntimeError("mamba_chunk_scan_combined: nheads must be a multiple of ngroups")
+    if 0 < SSD_CHUNKED_MIN_STATE <= n:
+        with torch.autocast(device_type="cuda", enabled=False):
+            return _SSDChunked.apply(x, dt, A, B, C, D, dt_bias, dt_softplus).to(x.dtype)
     dim = h * p
     u = x.float().reshape(b, l, dim).transpose(1, 2)                       # (b, dim, l), channel-last strides
     delta = dt.float().unsqueeze(-1).expand(b, l, h, p).reshape(b, l, dim).transpose(1, 2)
@@ -140,7 +232,8 @@ def ssd_scan_merge(mod, xc):
     B, H, W, conv_dim = xc.shape
     L, K = H * W, 4
     GN = mod.ngroups * mod.d_state
-    if SSD_PIXEL_ORDER and mod.ngroups == 1 and H * W < (1 << 22):
+    chunked = 0 < SSD_CHUNKED_MIN_STATE <= K * mod.d_state          # wide state: gathered sequences + chunked GEMMs
+    if SSD_PIXEL_ORDER and mod.ngroups == 1 and H * W < (1 << 22) and not chunked:
         # native path: the scan kernels take the four pixel orders themselves, one launch per direction's B/C slice
         from .ss2d_fused import ssd_scan_merge_pixel
         return ssd_scan_merge_pixel(xc, -torch.exp(mod.A_logs.float()), mod.Ds, mod.dt_bias.view(-1), mod.d_ssm, mod.d_state,

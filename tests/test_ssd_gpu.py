@@ -22,10 +22,16 @@ def close(got, want, tol, msg):
                                atol=max(1e-6, tol * float(np.abs(want).max())), err_msg=msg)
 
 
-@pytest.mark.parametrize("cfg", [(2, 30, 8, 64, 1, 64), (1, 49, 4, 16, 1, 16), (2, 65, 6, 8, 2, 24), (1, 7, 2, 64, 1, 5)])
+@pytest.mark.parametrize("cfg", [(2, 30, 8, 64, 1, 64), (1, 49, 4, 16, 1, 16), (2, 65, 6, 8, 2, 24), (1, 7, 2, 64, 1, 5),
+                                 (1, 300, 4, 8, 1, 40)])
 @pytest.mark.parametrize("hdim_D", [False, True])
-def test_chunk_scan_combined_vs_restatement(cfg, hdim_D):
+@pytest.mark.parametrize("chunked", [False, True])
+def test_chunk_scan_combined_vs_restatement(cfg, hdim_D, chunked, monkeypatch):
+    """Both evaluations of the operator -- the scan kernels (16 states per launch) and the chunked-GEMM (SSD) form -- against
+    the sequential float64 restatement, forward and every gradient."""
+    from medical_image_classification_amd import cnn_mamba as cm
     from medical_image_classification_amd.cnn_mamba import mamba_chunk_scan_combined
+    monkeypatch.setattr(cm, "SSD_CHUNKED_MIN_STATE", 1 if chunked else 0)
     b, l, h, p, g, n = cfg
     gen = torch.Generator().manual_seed(11)
     mk = lambda *s: torch.randn(*s, generator=gen)
@@ -158,8 +164,9 @@ def test_crossmamba_vs_restatement(cfg):
 @pytest.mark.parametrize("cfg", [(64, 16, 64, 9, 7, False), (32, 8, 16, 5, 12, True), (32, 40, 16, 5, 6, False),
                                  (64, 128, 64, 4, 5, False)])
 def test_ssd_pixel_order_kernels_match_gathered_path(cfg, monkeypatch):
-    """ssd_scan_merge through the pixel-order kernels (MS_SCAN_BC_MAP / MS_SCAN_ACCUMULATE, four launches on the conv
-    output itself) == the gathered-copies path (cross-scan materialised, plain operator): output and every gradient."""
+    """ssd_scan_merge through the pixel-order kernels (MS_SCAN_BC_MAP / MS_SCAN_ACCUMULATE, 4 x ceil(N/16) launches on the conv
+    output itself) and through the gathered sequences + chunked GEMMs == the gathered-copies path on the plain scan operator:
+    output and every gradient."""
     from medical_image_classification_amd import cnn_mamba as cm
     d_model, d_state, headdim, H, W, hdim_D = cfg
     torch.manual_seed(8)
@@ -170,18 +177,21 @@ def test_ssd_pixel_order_kernels_match_gathered_path(cfg, monkeypatch):
     u = torch.randn(2, H, W, d_model, device=dev())
     g = torch.randn(2, H, W, d_model, device=dev())
     res = {}
-    for flag in (True, False):
-        monkeypatch.setattr(cm, "SSD_PIXEL_ORDER", flag)
+    for name, pixel, min_state in (("pixel", True, 0), ("gathered", False, 0), ("chunked", False, 1)):
+        monkeypatch.setattr(cm, "SSD_PIXEL_ORDER", pixel)
+        monkeypatch.setattr(cm, "SSD_CHUNKED_MIN_STATE", min_state)
         m.zero_grad(set_to_none=True)
         ui = u.clone().requires_grad_()
         y = m(ui)
         y.backward(g)
-        res[flag] = (y.detach(), ui.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
-    (y1, du1, p1), (y0, du0, p0) = res[True], res[False]
-    close(y1, y0, 1e-4, "y")
-    close(du1, du0, 1e-3, "du")
-    for k in p0:
-        close(p1[k], p0[k], 1e-3, k)
+        res[name] = (y.detach(), ui.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    y0, du0, p0 = res["gathered"]
+    for name in ("pixel", "chunked"):
+        y1, du1, p1 = res[name]
+        close(y1, y0, 1e-4, f"{name} y")
+        close(du1, du0, 1e-3, f"{name} du")
+        for k in p0:
+            close(p1[k], p0[k], 1e-3, f"{name} {k}")
 
 
 def test_vfefm_small_matches_cpu_oracle():
