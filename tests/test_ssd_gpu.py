@@ -247,7 +247,8 @@ def test_vfefm_default_config_fusion_step_runs():
     for n, p in net.named_parameters():
         if p.grad is None:
             unused += 1
-            assert ".fusion.in_proj." in n or ".fusion.conv2d." in n, n     # constructed, never used (as in the reference)
+            # constructed, never used (as in the reference): CrossMamba's in_proj / conv2d, in_proj1/2 of the skip-less first decoder stage
+            assert ".fusion.in_proj." in n or ".fusion.conv2d." in n or n.startswith("layers_up.0.in_proj"), n
         else:
             assert torch.isfinite(p.grad).all().item(), n
     assert unused == 3 * 8 + 4
