@@ -40,9 +40,10 @@ _STATE_SLICE = 16      # states per kernel call (the backward kernels are built 
 
 # SSD as chunked matrix products (the "state space duality" form of Mamba-2, which the reference's dependency implements in
 # Triton): one launch set for ALL states instead of one scan launch per 16 states.  Used when the state is wide enough
-# for the GEMMs to win (measured: VFEFM's 512-state heads 2.15 s -> see DESIGN.md section 9); 0 = always the scan kernels.
-SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "64"))
-_SSD_CHUNK = 64
+# for the GEMMs to win: measured at 512 states (VFEFM, bs 32) 2.34 s -> 1.36 s per step; at 64 states (CNN_Mamba.VSSM,
+# bs 32) the scan kernels win, 46 vs 74 ms.  0 = always the scan kernels.
+SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "128"))
+_SSD_CHUNK = int(os.environ.get("MEDSCAN_SSD_CHUNK", "64"))      # positions per chunk (64 / 128 / 256 measured within 8 % of each other on VFEFM)
 
 
 def _ssd_chunked(x, dt, A, B, C, D, dt_bias, dt_softplus, Q=_SSD_CHUNK):

@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--d-state", type=int, default=128)
 ap.add_argument("--fp32", action="store_true")
+ap.add_argument("--profile", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -31,6 +32,11 @@ for i in range(a.warmup):
     fusion_step(net, opt, crit, vis, ir, ac); torch.cuda.synchronize()
     print(f"[bench_fusion +{time.perf_counter() - t0:.1f}s] warm-up step {i} done, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB",
           file=sys.stderr, flush=True)
+if a.profile:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fusion_step(net, opt, crit, vis, ir, ac); torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=90), file=sys.stderr, flush=True)
 ssi.TIMER.enabled = True
 torch.cuda.synchronize(); t1 = time.perf_counter()
 for _ in range(a.steps):
