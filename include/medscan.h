@@ -226,6 +226,16 @@ int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npi
 int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
                   int row_width, void *stream);
 
+/* ---- chunked (state-space-duality) SSD evaluation: the carry of chunk states (cnn_mamba._ssd_chunked) -----------------
+ * What mamba_ssm 2.2.2's `_state_passing_fwd/_bwd` Triton kernels do behind `mamba_chunk_scan_combined` (the call at
+ * CNN_Mamba.py:523-537; the dependency is outside the reference tree).
+ *   in, out : (batch, chunks, groups, dstate, heads_per_group, headdim) fp32 contiguous; decay : (batch, chunks, heads),
+ *             heads = groups * heads_per_group, the total decay exp(sum dt*A) of each chunk; headdim % 4 == 0.
+ *   reverse = 0 : out[z] = state entering chunk z    = decay[z-1] * out[z-1] + in[z-1],  out[0] = 0
+ *   reverse = 1 : out[z] = gradient reaching in[z]   = decay[z+1] * out[z+1] + in[z+1],  out[last] = 0   (the adjoint) */
+int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, int batch, int chunks, int groups, int dstate,
+                       int heads_per_group, int headdim, int reverse, void *stream);
+
 /* Diagnostic: one workgroup busy for `cycles` (< 2^32) shader clocks on `stream` -- used to test whether two streams
  * execute concurrently (medmamba.set_branch_streams). */
 int ms_spin(long long cycles, void *stream);

@@ -46,6 +46,38 @@ SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "128
 _SSD_CHUNK = int(os.environ.get("MEDSCAN_SSD_CHUNK", "64"))      # positions per chunk (64 / 128 / 256 measured within 8 % of each other on VFEFM)
 
 
+class _ChunkCarry(torch.autograd.Function):
+    """S_in[z] = decay[z-1] * S_in[z-1] + S[z-1] over the chunks (ms_ssd_chunk_carry), in the layout the state GEMMs use:
+    S (b, c, g, n, hg, p), decay (b, c, g*hg).  Backward = the same sweep run from the last chunk to the first."""
+
+    @staticmethod
+    def forward(ctx, S, decay):
+        _lib.require_cuda(S, decay)
+        b, c, g, n, hg, p = S.shape
+        S, decay = S.contiguous(), decay.contiguous()
+        out = torch.empty_like(S)
+        with _lib.on_device(S.device):
+            _lib.check(_lib.lib().ms_ssd_chunk_carry(S.data_ptr(), decay.data_ptr(), out.data_ptr(), b, c, g, n, hg, p, 0,
+                                                     _lib.current_stream_ptr(S.device)), "ms_ssd_chunk_carry")
+        ctx.save_for_backward(out, decay)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, decay = ctx.saved_tensors
+        b, c, g, n, hg, p = out.shape
+        dout = dout.contiguous()
+        dS = torch.empty_like(out)
+        with _lib.on_device(out.device):
+            _lib.check(_lib.lib().ms_ssd_chunk_carry(dout.data_ptr(), decay.data_ptr(), dS.data_ptr(), b, c, g, n, hg, p, 1,
+                                                     _lib.current_stream_ptr(out.device)), "ms_ssd_chunk_carry[reverse]")
+        ddecay = (dS * out).sum(dim=(3, 5)).view(b, c, g * hg)          # d/d decay[z] = <gradient reaching S[z], S_in[z]>
+        return dS, ddecay
+
+
+SSD_CARRY_KERNEL = os.environ.get("MEDSCAN_SSD_CARRY_KERNEL", "1") == "1"
+
+
 def _ssd_chunked(x, dt, A, B, C, D, dt_bias, dt_softplus, Q=_SSD_CHUNK):
     """h_t = exp(dt_t A) h_{t-1} + dt_t B_t (x) x_t,  y_t = C_t . h_t + D x_t, evaluated chunk-wise:
     inside a chunk   Y = ((C B^T) o L) X'          L[i,j] = exp(sum_{j<k<=i} dt_k A), i >= j   (X' = dt * x)
@@ -86,16 +118,21 @@ def _ssd_chunked(x, dt, A, B, C, D, dt_bias, dt_softplus, Q=_SSD_CHUNK):
     dec_in = torch.exp(cum[..., -1:] - cum)                         # (b,c,h,Q)
     Xs = (Xh * dec_in.view(b, nc, g, hg, Q, 1)).permute(0, 1, 2, 4, 3, 5).reshape(b, nc, g, Q, hg * p)
     S = torch.matmul(Bc.transpose(-1, -2), Xs)                      # (b,c,g,n,hg*p)
-    # carry across chunks: S_in[c] = sum_{c' < c} exp(sum_{c' < k < c} tot_k) S[c'],  tot = the chunks' total log-decays
-    tot = F.pad(cum[..., -1], (0, 0, 1, 0)).permute(0, 2, 1)       # (b,h,1+c): a leading zero for the (zero) initial state
-    ct = torch.cumsum(tot, dim=-1)
-    segc = ct.unsqueeze(-1) - ct.unsqueeze(-2)                      # (b,h,1+c,1+c)
-    tric = torch.ones(nc + 1, nc + 1, device=x.device, dtype=torch.bool).tril()
-    # Dc[b,h,z,c'] = exp(ct[z] - ct[c'+1]) for c' < z: what is left of chunk c''s end state when chunk z starts; 0 otherwise
-    Dc = torch.exp(segc.masked_fill(~tric, float("-inf")))[:, :, :-1, 1:]
-    Sh = S.view(b, nc, g, n, hg, p).permute(0, 2, 4, 1, 3, 5).reshape(b, h, nc, n * p)      # (b,h,c,n*p)
-    S_in = torch.matmul(Dc, Sh).view(b, g, hg, nc, n, p)            # (b,g,hg,z,n,p)
-    S_in = S_in.permute(0, 3, 1, 4, 2, 5).reshape(b, nc, g, n, hg * p)
+    if SSD_CARRY_KERNEL and x.is_cuda and p % 4 == 0:
+        # carry across chunks: S_in[z] = exp(tot[z-1]) S_in[z-1] + S[z-1] (tot = the chunks' total log-decays, per head): one
+        # sweep over the chunks in the GEMMs' own layout
+        S_in = _ChunkCarry.apply(S.view(b, nc, g, n, hg, p), torch.exp(cum[..., -1])).view(b, nc, g, n, hg * p)
+    else:
+        # carry across chunks: S_in[c] = sum_{c' < c} exp(sum_{c' < k < c} tot_k) S[c'],  tot = the chunks' total log-decays
+        tot = F.pad(cum[..., -1], (0, 0, 1, 0)).permute(0, 2, 1)       # (b,h,1+c): a leading zero for the (zero) initial state
+        ct = torch.cumsum(tot, dim=-1)
+        segc = ct.unsqueeze(-1) - ct.unsqueeze(-2)                      # (b,h,1+c,1+c)
+        tric = torch.ones(nc + 1, nc + 1, device=x.device, dtype=torch.bool).tril()
+        # Dc[b,h,z,c'] = exp(ct[z] - ct[c'+1]) for c' < z: what is left of chunk c''s end state when chunk z starts; 0 otherwise
+        Dc = torch.exp(segc.masked_fill(~tric, float("-inf")))[:, :, :-1, 1:]
+        Sh = S.view(b, nc, g, n, hg, p).permute(0, 2, 4, 1, 3, 5).reshape(b, h, nc, n * p)      # (b,h,c,n*p)
+        S_in = torch.matmul(Dc, Sh).view(b, g, hg, nc, n, p)            # (b,g,hg,z,n,p)
+        S_in = S_in.permute(0, 3, 1, 4, 2, 5).reshape(b, nc, g, n, hg * p)
     y_off = torch.matmul(Cc, S_in).view(b, nc, g, Q, hg, p).permute(0, 1, 2, 4, 3, 5)      # (b,c,g,hg,Q,p)
     y = y + y_off * torch.exp(cum).view(b, nc, g, hg, Q, 1)
     y = y.permute(0, 1, 4, 2, 3, 5).reshape(b, nc * Q, h, p)[:, :l]
