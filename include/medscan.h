@@ -232,9 +232,11 @@ int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, floa
  *   in, out : (batch, chunks, groups, dstate, heads_per_group, headdim) fp32 contiguous; decay : (batch, chunks, heads),
  *             heads = groups * heads_per_group, the total decay exp(sum dt*A) of each chunk; headdim % 4 == 0.
  *   reverse = 0 : out[z] = state entering chunk z    = decay[z-1] * out[z-1] + in[z-1],  out[0] = 0
- *   reverse = 1 : out[z] = gradient reaching in[z]   = decay[z+1] * out[z+1] + in[z+1],  out[last] = 0   (the adjoint) */
-int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, int batch, int chunks, int groups, int dstate,
-                       int heads_per_group, int headdim, int reverse, void *stream);
+ *   reverse = 1 : out[z] = gradient reaching in[z]   = decay[z+1] * out[z+1] + in[z+1],  out[last] = 0   (the adjoint);
+ *                 with `fwd_out` (the forward result) and `ddecay` (batch, chunks, heads; zero-filled by the caller) both
+ *                 non-NULL, also ddecay[z] += < out[z], fwd_out[z] > over the head's states (the gradient of `decay`). */
+int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
+                       int groups, int dstate, int heads_per_group, int headdim, int reverse, void *stream);
 
 /* Diagnostic: one workgroup busy for `cycles` (< 2^32) shader clocks on `stream` -- used to test whether two streams
  * execute concurrently (medmamba.set_branch_streams). */

@@ -107,7 +107,7 @@ def lib():
                                       c_i64, c_int, c_vp]
     h.ms_bn_relu_nhwc_bwd.argtypes = [c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]
     h.ms_bn_scratch_floats.argtypes = [c_int]
-    h.ms_ssd_chunk_carry.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp]
+    h.ms_ssd_chunk_carry.argtypes = [c_vp] * 5 + [c_int] * 7 + [c_vp]
     h.ms_spin.argtypes = [ctypes.c_longlong, c_vp]
     h.ms_status_string.restype = ctypes.c_char_p
     h.ms_status_string.argtypes = [ctypes.c_int]

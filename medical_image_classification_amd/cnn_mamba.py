@@ -57,7 +57,7 @@ class _ChunkCarry(torch.autograd.Function):
         S, decay = S.contiguous(), decay.contiguous()
         out = torch.empty_like(S)
         with _lib.on_device(S.device):
-            _lib.check(_lib.lib().ms_ssd_chunk_carry(S.data_ptr(), decay.data_ptr(), out.data_ptr(), b, c, g, n, hg, p, 0,
+            _lib.check(_lib.lib().ms_ssd_chunk_carry(S.data_ptr(), decay.data_ptr(), out.data_ptr(), None, None, b, c, g, n, hg, p, 0,
                                                      _lib.current_stream_ptr(S.device)), "ms_ssd_chunk_carry")
         ctx.save_for_backward(out, decay)
         return out
@@ -68,10 +68,11 @@ class _ChunkCarry(torch.autograd.Function):
         b, c, g, n, hg, p = out.shape
         dout = dout.contiguous()
         dS = torch.empty_like(out)
+        ddecay = torch.zeros_like(decay)               # d/d decay[z] = <gradient reaching S[z], S_in[z]>, reduced in the kernel
         with _lib.on_device(out.device):
-            _lib.check(_lib.lib().ms_ssd_chunk_carry(dout.data_ptr(), decay.data_ptr(), dS.data_ptr(), b, c, g, n, hg, p, 1,
+            _lib.check(_lib.lib().ms_ssd_chunk_carry(dout.data_ptr(), decay.data_ptr(), dS.data_ptr(), out.data_ptr(),
+                                                     ddecay.data_ptr(), b, c, g, n, hg, p, 1,
                                                      _lib.current_stream_ptr(out.device)), "ms_ssd_chunk_carry[reverse]")
-        ddecay = (dS * out).sum(dim=(3, 5)).view(b, c, g * hg)          # d/d decay[z] = <gradient reaching S[z], S_in[z]>
         return dS, ddecay
 
 

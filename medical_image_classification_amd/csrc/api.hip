@@ -15,8 +15,8 @@ int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const
 int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
                              int batch, int C, int H, int W, int64_t xps, hipStream_t s);
 int64_t dwconv_nhwc_bwd_scratch_floats(int batch, int C, int H, int W);
-int ssd_carry_dispatch(const float *in, const float *d, float *out, int batch, int chunks, int groups, int N, int hg, int P,
-                       int reverse, hipStream_t s);
+int ssd_carry_dispatch(const float *in, const float *d, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
+                       int groups, int N, int hg, int P, int reverse, hipStream_t s);
 int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int ndir,
                              int64_t dir_stride, const float *dy_extra, void *dx, int dx_bf16, int64_t dxps, float *scratch,
                              float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s);
@@ -160,9 +160,10 @@ int64_t ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(int batch, int C, int H, int W
 
 int ms_bn_scratch_floats(int C) { return ms::bn_scratch_floats(C); }
 
-int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, int batch, int chunks, int groups, int dstate,
-                       int heads_per_group, int headdim, int reverse, void *stream) {
-    return ms::ssd_carry_dispatch(in, decay, out, batch, chunks, groups, dstate, heads_per_group, headdim, reverse, (hipStream_t)stream);
+int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
+                       int groups, int dstate, int heads_per_group, int headdim, int reverse, void *stream) {
+    return ms::ssd_carry_dispatch(in, decay, out, fwd_out, ddecay, batch, chunks, groups, dstate, heads_per_group, headdim, reverse,
+                                  (hipStream_t)stream);
 }
 
 // One workgroup that keeps a CU busy for `cycles` shader clocks: a probe for whether two HIP streams really execute
