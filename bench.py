@@ -135,6 +135,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON result: anything a library writes to fd 1 meanwhile (RCCL prints a version
+    # banner there when its first communicator is created) is sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
     if world != args.gpus:
@@ -232,7 +237,10 @@ def main():
         elif world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline leg ...")
             out["cpu_baseline"] = cpu_baseline(args)
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,7 +23,9 @@ from .train import build_model, make_adam, synthetic_batch, train_step
 def setup_distributed(backend=None):
     """env:// rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; single process if they are unset
     (ddp_train.py:77-81).  Returns (distributed, rank, world_size, local_rank)."""
-    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+    # MEDSCAN_FORCE_DDP=1: build the process group and the DDP wrapper even for one rank (measures the wrapper's own cost)
+    force = os.environ.get("MEDSCAN_FORCE_DDP") == "1"
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and (int(os.environ["WORLD_SIZE"]) > 1 or force):
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         local_rank = int(os.environ.get("LOCAL_RANK", rank))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -37,11 +39,79 @@ def setup_distributed(backend=None):
     return False, 0, 1, int(os.environ.get("LOCAL_RANK", 0))
 
 
+class FlatGradDataParallel(nn.Module):
+    """Data-parallel wrapper with ONE gradient all-reduce per step over a flat fp32 buffer.
+
+    torch's DDP reducer pays per parameter: every backward it copies each of the 355 gradients into its bucket (a launch
+    each; autograd hands over freshly allocated gradient tensors, so `gradient_as_bucket_view` cannot avoid it), runs its
+    hooks and bucket bookkeeping, and broadcasts the BatchNorm buffers before every forward.  Measured on one MI355X with a
+    one-rank process group (MEDSCAN_FORCE_DDP=1): 27.1 ms per step against 24.9 ms without the wrapper -- an 8 % tax that
+    every N > 1 run would pay before a byte crosses xGMI.  MedMamba-T has only 57.8 MB of gradients (about 0.5 ms of
+    all-reduce on the xGMI mesh), so here: after backward the gradients are packed into one flat buffer with a multi-tensor
+    copy (a handful of launches), all-reduced ONCE (RCCL picks its own chunking for a message this size), scaled by
+    1/world, and handed to the optimizer as views of that buffer.  Same result as DDP (mean of the ranks' gradients).
+    Parameters and buffers are broadcast from rank 0 at construction, as DDP does; BatchNorm running statistics then stay
+    rank-local (they never enter the training arithmetic; `sync_buffers()` puts rank 0's on every rank -- ddp_train.main
+    calls it before each checkpoint -- which is the state torch DDP's per-forward broadcast converges to)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        self.world = dist.get_world_size()
+        self._broadcast([p.data for p in module.parameters()] + [b.data for b in module.buffers()])
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params or any(p.dtype != torch.float32 or p.device != self.params[0].device for p in self.params):
+            raise RuntimeError("FlatGradDataParallel needs fp32 parameters on one device (use MEDSCAN_DDP=torch otherwise)")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=self.params[0].device, dtype=torch.float32)
+        self.views = [v.view_as(p) for v, p in zip(self.flat.split([p.numel() for p in self.params]), self.params)]
+
+    @staticmethod
+    def _broadcast(tensors, src=0):
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        by_type = {}
+        for t in tensors:
+            by_type.setdefault((t.dtype, t.device), []).append(t)
+        for group in by_type.values():
+            flat = _flatten_dense_tensors(group)
+            dist.broadcast(flat, src)
+            for t, f in zip(group, _unflatten_dense_tensors(flat, group)):
+                t.copy_(f)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def sync_buffers(self):
+        bufs = [b.data for b in self.module.buffers()]
+        if bufs:
+            self._broadcast(bufs)
+
+    def reduce_gradients(self):
+        """Call between backward() and optimizer.step(): p.grad <- mean over ranks (train.train_step does)."""
+        src, dst, missing = [], [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                missing.append(v)                      # (unused this step: contributes zeros, as under DDP)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad); dst.append(v)
+        if missing:
+            torch._foreach_zero_(missing)
+        if src:
+            torch._foreach_copy_(dst, src)
+        dist.all_reduce(self.flat)
+        self.flat.mul_(1.0 / self.world)
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None:
+                p.grad = v
+
+
 def wrap_ddp(net, distributed, local_rank, on_cuda=True, broadcast_buffers=True):
-    """DDP(net, device_ids=[local_rank]) as in ddp_train.py:134; `gradient_as_bucket_view` avoids a grad copy
-    per bucket.  25 MiB buckets over the xGMI mesh: MedMamba-T's 57.8 MB of fp32 grads = 3-4 all-reduces/step."""
+    """The data-parallel wrapper of ddp_train.py:134.  Default: FlatGradDataParallel (one flat all-reduce per step);
+    MEDSCAN_DDP=torch: torch's DistributedDataParallel as the reference uses it (25 MiB buckets overlapped with backward,
+    `gradient_as_bucket_view`, buffers broadcast every forward)."""
     if not distributed:
         return net
+    if os.environ.get("MEDSCAN_DDP", "flat") != "torch":
+        return FlatGradDataParallel(net)
     if on_cuda:
         return DDP(net, device_ids=[local_rank], output_device=local_rank, gradient_as_bucket_view=True,
                    broadcast_buffers=broadcast_buffers)
@@ -95,6 +165,8 @@ def main(argv=None):
             running += train_step(ddp_net, optimizer, loss_function, images, labels,
                                   torch.bfloat16 if args.bf16 else None).item()
             set_branch_streams(True)            # opt-in (MEDSCAN_BRANCH_STREAMS=late): two-stream blocks after the first step
+        if hasattr(ddp_net, "sync_buffers"):
+            ddp_net.sync_buffers()              # rank 0's BatchNorm statistics everywhere before they are saved / evaluated
         if rank == 0:
             print(f"[epoch {epoch + 1}] train_loss: {running / args.steps_per_epoch:.3f}")
             torch.save({"epoch": epoch, "model": net.state_dict(), "optimizer": optimizer.state_dict(),

@@ -49,6 +49,8 @@ def train_step(net, optimizer, loss_function, images, labels, autocast_dtype=Non
     else:
         loss = loss_function(net(images), labels)
     loss.backward()
+    if hasattr(net, "reduce_gradients"):           # ddp_train.FlatGradDataParallel: one flat all-reduce per step
+        net.reduce_gradients()
     optimizer.step()
     return loss
 

@@ -14,8 +14,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_ddp_world2_gloo():
-    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+import pytest
+
+
+@pytest.mark.parametrize("impl", ["flat", "torch"])
+def test_ddp_world2_gloo(impl):
+    """Both data-parallel wrappers (the flat single all-reduce, default; torch DDP as the reference uses it)."""
+    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT, MEDSCAN_DDP=impl)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_ddp_worker.py")]

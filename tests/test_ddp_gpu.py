@@ -1,0 +1,47 @@
+"""The data-parallel wrapper on the GPU with a one-rank RCCL process group (the N > 1 semantics are covered on CPU with
+world_size 2 over gloo, tests/test_ddp_cpu.py): same training trajectory as the unwrapped model, gradients handed to the
+optimizer as views of the flat all-reduce buffer."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_flat_grad_data_parallel_one_rank_matches_plain_training():
+    from medical_image_classification_amd import medmamba as mm
+    from medical_image_classification_amd.ddp_train import FlatGradDataParallel
+    from medical_image_classification_amd.train import make_adam, train_step
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        def run(wrap):
+            torch.manual_seed(3)
+            net = mm.VSSM(depths=[1, 1], dims=[32, 64], num_classes=4, drop_path_rate=0.0).to(dev).train()
+            model = FlatGradDataParallel(net) if wrap else net
+            opt = make_adam(net.parameters(), lr=1e-3)
+            g = torch.Generator(device=dev).manual_seed(5)
+            x = torch.randn(4, 3, 64, 64, device=dev, generator=g)
+            y = torch.randint(0, 4, (4,), device=dev, generator=g)
+            losses = [train_step(model, opt, torch.nn.CrossEntropyLoss(), x, y, torch.bfloat16).item() for _ in range(3)]
+            return net, model, losses
+        net0, _, l0 = run(False)
+        net1, ddp, l1 = run(True)
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ddp.params, ddp.views) if p.grad is not None)
+        ddp.sync_buffers()
+        # atomics make the kernels' summation order run-to-run variable: equal to rounding, not bitwise
+        assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
+        for (n, p), (_, q) in zip(net0.named_parameters(), net1.named_parameters()):
+            assert float((p - q).abs().max()) <= 5e-3 * max(1e-2, float(p.abs().max())), n
+    finally:
+        dist.destroy_process_group()
