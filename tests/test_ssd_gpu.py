@@ -297,3 +297,31 @@ def test_chunked_ssd_carry_as_gemm_matches_kernel(monkeypatch):
         res.append([y.detach()] + [t.grad for t in ins])
     for a, r, name in zip(res[0], res[1], ("y", "dx", "ddt", "dA", "dB", "dC")):
         close(a, r, 1e-4, name)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_stem_batchnorm_matches_nn_batchnorm(bf16):
+    """ConvTConvPW._bn (reductions + affine pass) == nn.BatchNorm2d in training mode: output, input/weight/bias gradients,
+    running statistics and the batch counter."""
+    from medical_image_classification_amd.cnn_mamba import ConvTConvPW
+    torch.manual_seed(2)
+    stem = ConvTConvPW(in_channels=3).to(dev()).train()
+    ref = torch.nn.BatchNorm2d(3).to(dev()).train()
+    with torch.no_grad():
+        stem.bn.weight.uniform_(0.5, 1.5); stem.bn.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(stem.bn.weight); ref.bias.copy_(stem.bn.bias)
+    x = torch.randn(4, 3, 40, 36, device=dev()) * 2 + 0.5
+    if bf16:
+        x = x.bfloat16()
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    g = torch.randn_like(x)
+    ya, yb = stem._bn(xa), ref(xb)
+    assert ya.dtype == yb.dtype
+    ya.backward(g); yb.backward(g)
+    tol = 2e-2 if bf16 else 1e-5
+    close(ya, yb, tol, "y"); close(xa.grad, xb.grad, tol, "dx")
+    close(stem.bn.weight.grad, ref.weight.grad, 2e-3 if bf16 else 1e-4, "dweight"); close(stem.bn.bias.grad, ref.bias.grad, 2e-3 if bf16 else 1e-4, "dbias")
+    close(stem.bn.running_mean, ref.running_mean, 1e-5, "running_mean"); close(stem.bn.running_var, ref.running_var, 1e-5, "running_var")
+    assert int(stem.bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    stem.eval()
+    assert torch.equal(stem._bn(x), stem.bn(x))                          # eval mode: the module itself
