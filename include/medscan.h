@@ -226,6 +226,19 @@ int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npi
 int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
                   int row_width, void *stream);
 
+/* ---- gated RMS normalisation of the SSD blocks (mamba_ssm 2.2.2 `RMSNormGated`, norm_before_gate=False, one group, as
+ * constructed at CNN_Mamba.py:430-431 and applied at :554-555), optionally with the cross-merge sum (:542-552) in front:
+ *   y    : ndir (1 or 4) slabs of (npix, D) fp32, `dir_stride` elements apart; merged = y0 or ((y0 + y2) + y1) + y3
+ *   z    : gate, (npix, *) fp32 or bf16 with pixel stride z_pixel_stride;   weight (D);   D <= 1024
+ *   fwd  : out = g * rsqrt(mean_D(g^2) + eps) * weight,  g = merged * silu(z);  out (npix, D) fp32 or bf16
+ *   bwd  : dy (npix, D) fp32 = gradient of `merged` (the same for every slab), dz (like z, own pixel stride), dweight (D)
+ *          ACCUMULATED (zero-fill first). */
+int ms_rms_gate_fwd(const float *y, int64_t dir_stride, int ndir, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                    const float *weight, float eps, void *out, int out_is_bf16, int64_t npix, int D, void *stream);
+int ms_rms_gate_bwd(const float *y, int64_t dir_stride, int ndir, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                    const float *weight, float eps, const void *dout, int dout_is_bf16, float *dy, void *dz,
+                    int64_t dz_pixel_stride, float *dweight, int64_t npix, int D, void *stream);
+
 /* ---- chunked (state-space-duality) SSD evaluation: the carry of chunk states (cnn_mamba._ssd_chunked) -----------------
  * What mamba_ssm 2.2.2's `_state_passing_fwd/_bwd` Triton kernels do behind `mamba_chunk_scan_combined` (the call at
  * CNN_Mamba.py:523-537; the dependency is outside the reference tree).

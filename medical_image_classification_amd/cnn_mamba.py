@@ -206,6 +206,61 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt
     return y.transpose(1, 2).reshape(b, l, h, p).to(x.dtype)
 
 
+def _rows_view(t, D):
+    """(..., D) tensor (possibly a channel slice of a wider tensor) -> (tensor, row stride) usable by the row kernels."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    ps = t.stride(-2) if t.dim() >= 2 else D
+    ok = t.stride(-1) == 1 and ps >= D
+    exp = ps
+    for k in range(t.dim() - 2, -1, -1):                 # leading dims must collapse onto one uniform row stride
+        ok = ok and (t.shape[k] == 1 or t.stride(k) == exp)
+        exp *= t.shape[k]
+    if not ok:
+        t = t.contiguous(); ps = D
+    return t, ps
+
+
+class _RMSNormGate(torch.autograd.Function):
+    """rmsnorm(y * silu(z)) * weight as one kernel each way (ms_rms_gate_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, y, z, weight, eps, out_dtype):
+        _lib.require_cuda(y, z, weight)
+        D = y.shape[-1]
+        y = y.float().contiguous()
+        z, zps = _rows_view(z, D)
+        w = weight.detach().float().contiguous()
+        npix = y.numel() // D
+        out = torch.empty(y.shape, device=y.device, dtype=out_dtype)
+        with _lib.on_device(y.device):
+            _lib.check(_lib.lib().ms_rms_gate_fwd(y.data_ptr(), 0, 1, z.data_ptr(), int(z.dtype == torch.bfloat16), zps, w.data_ptr(),
+                                                  float(eps), out.data_ptr(), int(out_dtype == torch.bfloat16), npix, D,
+                                                  _lib.current_stream_ptr(y.device)), "ms_rms_gate_fwd")
+        ctx.save_for_backward(y, z, w)
+        ctx.geom = (float(eps), zps, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, z, w = ctx.saved_tensors
+        eps, zps, wdtype = ctx.geom
+        D = y.shape[-1]
+        npix = y.numel() // D
+        if dout.dtype not in (torch.float32, torch.bfloat16):
+            dout = dout.float()
+        dout = dout.contiguous()
+        dy = torch.empty_like(y)
+        dz = torch.empty(y.shape, device=y.device, dtype=z.dtype)
+        dw = torch.zeros_like(w)
+        with _lib.on_device(y.device):
+            _lib.check(_lib.lib().ms_rms_gate_bwd(y.data_ptr(), 0, 1, z.data_ptr(), int(z.dtype == torch.bfloat16), zps, w.data_ptr(),
+                                                  eps, dout.data_ptr(), int(dout.dtype == torch.bfloat16), dy.data_ptr(),
+                                                  dz.data_ptr(), D, dw.data_ptr(), npix, D,
+                                                  _lib.current_stream_ptr(y.device)), "ms_rms_gate_bwd")
+        return dy, dz, dw.to(wdtype), None, None
+
+
 class RMSNormGated(nn.Module):
     """mamba_ssm.ops.triton.layernorm_gated.RMSNorm as constructed at CNN_Mamba.py:430-431:
     norm_before_gate=False -> y = rmsnorm(x * silu(z)) * weight, one group, no bias."""
@@ -218,8 +273,13 @@ class RMSNormGated(nn.Module):
         self.group_size = group_size
         self.norm_before_gate = norm_before_gate
 
-    def forward(self, x, z=None):
-        dt = x.dtype
+    def forward(self, x, z=None, out_dtype=None):
+        """`out_dtype` (not in the reference signature): the dtype the consumer wants; default x.dtype as the reference."""
+        dt = x.dtype if out_dtype is None else out_dtype
+        D = x.shape[-1]
+        if x.is_cuda and z is not None and not self.norm_before_gate and (self.group_size or D) == D and D <= 1024 \
+                and dt in (torch.float32, torch.bfloat16) and tuple(z.shape) == tuple(x.shape):
+            return _RMSNormGate.apply(x, z, self.weight, self.eps, dt)
         x = x.float()
         if z is not None and not self.norm_before_gate:
             x = x * F.silu(z.float())
@@ -319,7 +379,9 @@ def ssd_scan_merge(mod, xc):
 def ssd_tail(mod, out, z, z0, x0, d_mlp):
     """RMSNormGated, optional gated-MLP concat, out_proj, dropout (CNN_Mamba.py:554-564)."""
     if mod.rmsnorm:
-        out = mod.norm(out, z)
+        # straight into the dtype out_proj consumes when nothing else is concatenated in front of it
+        bf16 = d_mlp == 0 and out.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        out = mod.norm(out, z, out_dtype=torch.bfloat16 if bf16 else None)
     if d_mlp > 0:
         out = torch.cat([F.silu(z0) * x0, out], dim=-1)
     out_data = mod.out_proj(out)

@@ -15,6 +15,11 @@ int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const
 int dwconv_nhwc_fwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, float *y,
                              int batch, int C, int H, int W, int64_t xps, hipStream_t s);
 int64_t dwconv_nhwc_bwd_scratch_floats(int batch, int C, int H, int W);
+int rms_gate_fwd_dispatch(const float *y4, int64_t sk, int ndir, const void *z, int z_bf16, int64_t zps, const float *w, float eps,
+                          void *out, int out_bf16, int64_t npix, int D, hipStream_t s);
+int rms_gate_bwd_dispatch(const float *y4, int64_t sk, int ndir, const void *z, int z_bf16, int64_t zps, const float *w, float eps,
+                          const void *dout, int dout_bf16, float *dy, void *dz, int64_t dzps, float *dweight, int64_t npix, int D,
+                          hipStream_t s);
 int ssd_carry_dispatch(const float *in, const float *d, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
                        int groups, int N, int hg, int P, int reverse, hipStream_t s);
 int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const float *bias, const float *dy, int ndir,
@@ -159,6 +164,19 @@ int64_t ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(int batch, int C, int H, int W
 }
 
 int ms_bn_scratch_floats(int C) { return ms::bn_scratch_floats(C); }
+
+int ms_rms_gate_fwd(const float *y, int64_t dir_stride, int ndir, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                    const float *weight, float eps, void *out, int out_is_bf16, int64_t npix, int D, void *stream) {
+    return ms::rms_gate_fwd_dispatch(y, dir_stride, ndir, z, z_is_bf16, z_pixel_stride, weight, eps, out, out_is_bf16, npix, D,
+                                     (hipStream_t)stream);
+}
+
+int ms_rms_gate_bwd(const float *y, int64_t dir_stride, int ndir, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                    const float *weight, float eps, const void *dout, int dout_is_bf16, float *dy, void *dz,
+                    int64_t dz_pixel_stride, float *dweight, int64_t npix, int D, void *stream) {
+    return ms::rms_gate_bwd_dispatch(y, dir_stride, ndir, z, z_is_bf16, z_pixel_stride, weight, eps, dout, dout_is_bf16, dy, dz,
+                                     dz_pixel_stride, dweight, npix, D, (hipStream_t)stream);
+}
 
 int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
                        int groups, int dstate, int heads_per_group, int headdim, int reverse, void *stream) {

@@ -325,3 +325,37 @@ def test_stem_batchnorm_matches_nn_batchnorm(bf16):
     assert int(stem.bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
     stem.eval()
     assert torch.equal(stem._bn(x), stem.bn(x))                          # eval mode: the module itself
+
+
+@pytest.mark.parametrize("cfg", [(2, 5, 7, 96), (1, 3, 3, 1024), (3, 2, 5, 70), (1, 1, 1, 130), (2, 9, 4, 256)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_rms_gate_kernels_vs_restatement(cfg, bf16):
+    """RMSNormGated(norm_before_gate=False) through ms_rms_gate_fwd / _bwd against the float64 restatement: output and the
+    gradients of x, z (a strided channel slice of a wider tensor, as in the modules) and weight."""
+    from medical_image_classification_amd.cnn_mamba import RMSNormGated
+    B, H, W, D = cfg
+    gen = torch.Generator().manual_seed(D + H)
+    x = torch.randn(B, H, W, D, generator=gen)
+    wide = torch.randn(B, H, W, D + 24, generator=gen)
+    g = torch.randn(B, H, W, D, generator=gen)
+    wt = torch.randn(D, generator=gen)
+    if bf16:
+        wide, g = wide.bfloat16().float(), g.bfloat16().float()
+    xr, zr, wr = x.double().requires_grad_(), wide[..., 8:8 + D].double().requires_grad_(), wt.double().requires_grad_()
+    ref = ssd_oracle.rmsnorm_gated_ref(xr, zr, wr, 1e-5, False)
+    ref.backward(g.double())
+    n = RMSNormGated(D, eps=1e-5, norm_before_gate=False, group_size=D).to(dev())
+    with torch.no_grad():
+        n.weight.copy_(wt)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    xd = x.to(dev()).requires_grad_()
+    wided = wide.to(dev(), dt).requires_grad_()
+    out = n(xd, wided[..., 8:8 + D], out_dtype=dt)
+    assert out.dtype == dt
+    out.backward(g.to(dev(), dt))
+    tol = 2e-2 if bf16 else 1e-4
+    close(out, ref, tol, "out")
+    close(xd.grad, xr.grad, tol, "dx")
+    close(wided.grad[..., 8:8 + D], zr.grad, tol, "dz")
+    assert float(wided.grad[..., :8].abs().max()) == 0.0
+    close(n.weight.grad, wr.grad, 1e-3 if not bf16 else 1e-2, "dweight")
