@@ -43,6 +43,11 @@ _STATE_SLICE = 16      # states per kernel call (the backward kernels are built 
 # for the GEMMs to win: measured at 512 states (VFEFM, bs 32) 2.34 s -> 1.36 s per step; at 64 states (CNN_Mamba.VSSM,
 # bs 32) the scan kernels win, 46 vs 74 ms.  0 = always the scan kernels.
 SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "128"))
+# Scans whose chunk-state tensor is at most this large keep their intermediates for backward (plain autograd); larger ones
+# keep only their operands and recompute (_SSDChunked).  Measured on VFEFM bs 32 (ms/step, peak HBM): 0 GB 883 / 52 GiB,
+# 0.5 GB 861 / 58, 1 GB 816 / 97, 2 GB 798 / 141, everything kept 1056* / 250 (*before the carry kernel).  288 GB of HBM3E
+# is there to be used: 2 GB.
+SSD_KEEP_STATE_BYTES = int(float(os.environ.get("MEDSCAN_SSD_KEEP_STATE_GB", "2")) * 2 ** 30)
 _SSD_CHUNK = int(os.environ.get("MEDSCAN_SSD_CHUNK", "64"))      # positions per chunk (64 / 128 / 256 measured within 8 % of each other on VFEFM)
 
 
@@ -184,6 +189,11 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt
         raise RuntimeError("mamba_chunk_scan_combined: nheads must be a multiple of ngroups")
     if 0 < SSD_CHUNKED_MIN_STATE <= n:
         with torch.autocast(device_type="cuda", enabled=False):
+            # the chunk-state tensors ((l / chunk) x n x h*p floats per sample; autograd would keep ~5 of them) decide whether
+            # the scan keeps its intermediates or only its operands
+            state_bytes = 4 * b * ((l + _SSD_CHUNK - 1) // _SSD_CHUNK) * n * h * p
+            if state_bytes <= SSD_KEEP_STATE_BYTES:
+                return _ssd_chunked(x, dt, A, B, C, D, dt_bias, dt_softplus).to(x.dtype)
             return _SSDChunked.apply(x, dt, A, B, C, D, dt_bias, dt_softplus).to(x.dtype)
     dim = h * p
     u = x.float().reshape(b, l, dim).transpose(1, 2)                       # (b, dim, l), channel-last strides
