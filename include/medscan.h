@@ -127,6 +127,12 @@ int ms_scan_n_chunks(int seqlen);
  */
 int ms_cross_scan(const float *x, float *xs, int batch, int dim, int H, int W, void *stream);
 int ms_cross_merge(const float *ys, float *y, int batch, int dim, int H, int W, void *stream);
+/* The same on channel-LAST tensors, as the SSD blocks use them (CNN_Mamba.py:494-519 gather, :542-552 inverse + adds):
+ *   cross_scan_nhwc : pix (batch, H*W, *) fp32, first C columns of rows `pixel_stride` apart -> seq (batch, H*W, 4, C)
+ *   cross_merge_nhwc: seq (batch, H*W, 4, C) -> pix[b, p, 0:C] = ((s0 + s2) + s1) + s3 at the steps that visit pixel p
+ * (a column range of a wider tensor on the pixel side: pass the pointer of its first column). */
+int ms_cross_scan_nhwc(const float *pix, int64_t pixel_stride, float *seq, int batch, int H, int W, int C, void *stream);
+int ms_cross_merge_nhwc(const float *seq, float *pix, int64_t pixel_stride, int batch, int H, int W, int C, void *stream);
 
 /*
  * Depthwise 3x3 conv (padding 1, stride 1) + bias + SiLU, NCHW fp32 contiguous

@@ -47,7 +47,7 @@ class MsScanBwdParams(ctypes.Structure):
 
 
 EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_cross_scan",
-           "ms_cross_merge", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_dwconv3x3_silu_nhwc_fwd",
+           "ms_cross_merge", "ms_cross_scan_nhwc", "ms_cross_merge_nhwc", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_dwconv3x3_silu_nhwc_fwd",
            "ms_dwconv3x3_silu_nhwc_bwd", "ms_dwconv3x3_silu_nhwc_bwd_scratch_floats", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_bwd", "ms_bn_relu_nhwc_fwd",
            "ms_bn_relu_nhwc_bwd", "ms_bn_scratch_floats", "ms_ssd_chunk_carry", "ms_rms_gate_fwd", "ms_rms_gate_bwd", "ms_spin", "ms_abi_version", "ms_status_string")
@@ -87,6 +87,8 @@ def lib():
     h.ms_scan_n_chunks.argtypes = [ctypes.c_int]
     h.ms_cross_scan.argtypes = [c_vp, c_vp] + [ctypes.c_int] * 4 + [c_vp]
     h.ms_cross_merge.argtypes = [c_vp, c_vp] + [ctypes.c_int] * 4 + [c_vp]
+    h.ms_cross_scan_nhwc.argtypes = [c_vp, c_i64, c_vp] + [ctypes.c_int] * 4 + [c_vp]
+    h.ms_cross_merge_nhwc.argtypes = [c_vp, c_vp, c_i64] + [ctypes.c_int] * 4 + [c_vp]
     h.ms_dwconv3x3_silu_fwd.argtypes = [c_vp] * 4 + [ctypes.c_int] * 4 + [c_vp]
     h.ms_dwconv3x3_silu_bwd.argtypes = [c_vp] * 7 + [ctypes.c_int] * 4 + [c_vp]
     h.ms_dwconv3x3_silu_nhwc_fwd.argtypes = [c_vp, ctypes.c_int] + [c_vp] * 3 + [ctypes.c_int] * 4 + [c_i64, c_vp]

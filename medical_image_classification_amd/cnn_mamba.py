@@ -351,6 +351,72 @@ def _scan_orders(H, W, device):
     return idx, inv
 
 
+class _SeqFromPixels(torch.autograd.Function):
+    """Column ranges of the channel-last conv output -> their four scan sequences (ms_cross_scan_nhwc), one contiguous
+    (B, L, 4, width) tensor per range -- exactly the layouts the SSD operator takes (CNN_Mamba.py:506-519) -- and, backward,
+    the 4-term sums written straight into the column ranges of ONE gradient tensor (ms_cross_merge_nhwc)."""
+
+    @staticmethod
+    def forward(ctx, xc, widths):
+        _lib.require_cuda(xc)
+        B, H, W, conv = xc.shape
+        xc = xc.float().contiguous()
+        lib, stream = _lib.lib(), _lib.current_stream_ptr(xc.device)
+        outs, col = [], 0
+        with _lib.on_device(xc.device):
+            for w in widths:
+                o = torch.empty((B, H * W, 4, w), device=xc.device, dtype=torch.float32)
+                _lib.check(lib.ms_cross_scan_nhwc(xc.data_ptr() + 4 * col, conv, o.data_ptr(), B, H, W, w, stream), "ms_cross_scan_nhwc")
+                outs.append(o); col += w
+        assert col == conv
+        ctx.geom = (B, H, W, conv, tuple(widths))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, H, W, conv, widths = ctx.geom
+        dev = next(g for g in grads if g is not None).device
+        dxc = torch.empty((B, H, W, conv), device=dev, dtype=torch.float32)
+        lib, stream = _lib.lib(), _lib.current_stream_ptr(dev)
+        col = 0
+        with _lib.on_device(dev):
+            for w, g in zip(widths, grads):
+                if g is None:
+                    dxc[..., col:col + w] = 0
+                else:
+                    g = g.float().contiguous()
+                    _lib.check(lib.ms_cross_merge_nhwc(g.data_ptr(), dxc.data_ptr() + 4 * col, conv, B, H, W, w, stream), "ms_cross_merge_nhwc")
+                col += w
+        return dxc, None
+
+
+class _PixelsFromSeq(torch.autograd.Function):
+    """(B, L, 4, d) per-direction results in scan order -> (B, L, d) in pixel order, ((y0 + y2) + y1) + y3 (CNN_Mamba.py:542-552)."""
+
+    @staticmethod
+    def forward(ctx, y, H, W):
+        _lib.require_cuda(y)
+        B, L, K, d = y.shape
+        y = y.float().contiguous()
+        out = torch.empty((B, L, d), device=y.device, dtype=torch.float32)
+        with _lib.on_device(y.device):
+            _lib.check(_lib.lib().ms_cross_merge_nhwc(y.data_ptr(), out.data_ptr(), d, B, H, W, d, _lib.current_stream_ptr(y.device)),
+                       "ms_cross_merge_nhwc")
+        ctx.geom = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.geom
+        B, L, d = g.shape
+        g = g.float().contiguous()
+        dy = torch.empty((B, L, 4, d), device=g.device, dtype=torch.float32)
+        with _lib.on_device(g.device):
+            _lib.check(_lib.lib().ms_cross_scan_nhwc(g.data_ptr(), d, dy.data_ptr(), B, H, W, d, _lib.current_stream_ptr(g.device)),
+                       "ms_cross_scan_nhwc")
+        return dy, None, None
+
+
 def ssd_scan_merge(mod, xc):
     """Shared core of SS2D_with_SSD.forward (CNN_Mamba.py:494-552) and CrossMamba.forward.mamba_core
     (CrossMamba_fusion_2b2.py:283-349): xc (B,H,W,conv_dim) = SiLU(dwconv([x | B | C | dt])) channel-last, fp32 ->
@@ -365,25 +431,18 @@ def ssd_scan_merge(mod, xc):
         from .ss2d_fused import ssd_scan_merge_pixel
         return ssd_scan_merge_pixel(xc, -torch.exp(mod.A_logs.float()), mod.Ds, mod.dt_bias.view(-1), mod.d_ssm, mod.d_state,
                                     mod.nheads, mod.headdim, mod.D_has_hdim)
-    # general path (ngroups > 1): 4-direction cross-scan as a gather of pixels (CNN_Mamba.py:494-498): (B, L, 4, conv_dim) in scan order
-    idx, inv = _scan_orders(H, W, xc.device)
-    xs4 = xc.reshape(B, L, conv_dim)[:, idx.reshape(-1)].view(B, K, L, conv_dim).transpose(1, 2)
-    xs, Bs, Cs, dts = torch.split(xs4, [mod.d_ssm, GN, GN, mod.nheads], dim=-1)
-    # layouts of CNN_Mamba.py:506-519: heads = (direction, head); B/C = the four directions' states concatenated
-    xs = xs.reshape(B, L, K * mod.nheads, mod.headdim)
-    dts = dts.reshape(B, L, K * mod.nheads)
-    Bs = Bs.reshape(B, L, mod.ngroups, -1)          # flat (k, g, n) order regrouped as "(g n)", as :517-519 does
-    Cs = Cs.reshape(B, L, mod.ngroups, -1)
+    # sequence path (wide states / ngroups > 1 / MEDSCAN_SSD_PIXEL=0): the four scan orders materialised channel-last
+    # (CNN_Mamba.py:494-498), each operand straight in the layout of :506-519 -- heads = (direction, head); B/C = the four
+    # directions' states, flat (k, g, n) order regrouped as "(g n)" as :517-519 does
+    xs, Bs, Cs, dts = _SeqFromPixels.apply(xc, (mod.d_ssm, GN, GN, mod.nheads))
     As = -torch.exp(mod.A_logs.float())
     Ds = mod.Ds.view(-1, mod.headdim) if mod.D_has_hdim else mod.Ds
-    y = mamba_chunk_scan_combined(xs.float(), dts.float(), As, Bs.float(), Cs.float(), chunk_size=mod.chunk_size,
+    y = mamba_chunk_scan_combined(xs.view(B, L, K * mod.nheads, mod.headdim), dts.view(B, L, K * mod.nheads), As,
+                                  Bs.view(B, L, mod.ngroups, -1), Cs.view(B, L, mod.ngroups, -1), chunk_size=mod.chunk_size,
                                   D=Ds, z=None, dt_bias=mod.dt_bias.view(-1), dt_softplus=True)
-    y = y.reshape(B, L, K, mod.d_ssm)
     assert y.dtype == torch.float
-    # cross-merge (CNN_Mamba.py:542-552): bring every direction back to pixel order and add, ((y1+y2)+y3)+y4
-    yk = [y[:, inv[k], k] for k in range(K)]
-    out = ((yk[0] + yk[2]) + yk[1]) + yk[3]
-    return out.view(B, H, W, -1)
+    # cross-merge (CNN_Mamba.py:542-552): every direction back to pixel order and added, ((y1+y2)+y3)+y4
+    return _PixelsFromSeq.apply(y.reshape(B, L, K, mod.d_ssm), H, W).view(B, H, W, -1)
 
 
 def ssd_tail(mod, out, z, z0, x0, d_mlp):

@@ -8,6 +8,8 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream);
 int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream);
 int cross_scan_dispatch(const float *x, float *xs, int batch, int dim, int H, int W, hipStream_t s);
 int cross_merge_dispatch(const float *ys, float *y, int batch, int dim, int H, int W, hipStream_t s);
+int cross_scan_nhwc_dispatch(const float *pix, int64_t pps, float *seq, int batch, int H, int W, int C, hipStream_t s);
+int cross_merge_nhwc_dispatch(const float *seq, float *pix, int64_t pps, int batch, int H, int W, int C, hipStream_t s);
 int dwconv_fwd_dispatch(const float *x, const float *w, const float *bias, float *y,
                         int batch, int C, int H, int W, hipStream_t s);
 int dwconv_bwd_dispatch(const float *x, const float *w, const float *bias, const float *dy, float *dx,
@@ -66,6 +68,14 @@ int ms_scan_n_chunks(int seqlen) { return seqlen <= 0 ? 0 : (seqlen + MS_SCAN_CH
 
 int ms_cross_scan(const float *x, float *xs, int batch, int dim, int H, int W, void *stream) {
     return ms::cross_scan_dispatch(x, xs, batch, dim, H, W, (hipStream_t)stream);
+}
+
+int ms_cross_scan_nhwc(const float *pix, int64_t pixel_stride, float *seq, int batch, int H, int W, int C, void *stream) {
+    return ms::cross_scan_nhwc_dispatch(pix, pixel_stride, seq, batch, H, W, C, (hipStream_t)stream);
+}
+
+int ms_cross_merge_nhwc(const float *seq, float *pix, int64_t pixel_stride, int batch, int H, int W, int C, void *stream) {
+    return ms::cross_merge_nhwc_dispatch(seq, pix, pixel_stride, batch, H, W, C, (hipStream_t)stream);
 }
 
 int ms_cross_merge(const float *ys, float *y, int batch, int dim, int H, int W, void *stream) {

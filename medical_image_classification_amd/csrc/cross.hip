@@ -82,4 +82,72 @@ int cross_merge_dispatch(const float *ys, float *y, int batch, int dim, int H, i
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
+// ---- channel-last variants: pixels (B, H*W, *) <-> the four scan sequences (B, H*W, 4, C) ---------------------------------
+// The SSD blocks (CNN_Mamba.py:494-519,542-552) gather the conv output [x | B | C | dt] of every pixel into the four scan
+// orders with stack/transpose/flip/cat and bring the results back with the inverse permutations and three adds.  Channel-
+// last both sides, so a (pixel, column range) row moves as one coalesced segment: the scan is a gather (each output row
+// reads one pixel), the merge a 4-term sum per pixel in the reference's add order -- each the other's adjoint.
+//   seq[b, l, 0, c] = pix[b, l, c]                  seq[b, l, 2, c] = pix[b, L-1-l, c]
+//   seq[b, l, 1, c] = pix[b, (l % H) * W + l / H, c]   seq[b, l, 3, c] = pix[b, col(L-1-l), c]
+__device__ __forceinline__ int seq_pixel(int k, int l, int H, int W, int L) {
+    const int t = (k & 2) ? L - 1 - l : l;
+    return (k & 1) ? (t % H) * W + t / H : t;
+}
+__device__ __forceinline__ int pixel_seq(int k, int pix, int H, int W, int L) {          // inverse of seq_pixel
+    const int t = (k & 1) ? (pix % W) * H + pix / W : pix;
+    return (k & 2) ? L - 1 - t : t;
+}
+
+__global__ void __launch_bounds__(256)
+cross_scan_nhwc_kernel(const float *__restrict__ pix, int64_t pps, float *__restrict__ seq, int H, int W, int C, int64_t total) {
+    const int L = H * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t r = e / C;                      // (b * L + l) * 4 + k
+        const int k = (int)(r & 3);
+        const int64_t bl = r >> 2;
+        const int l = (int)(bl % L);
+        const int64_t b = bl / L;
+        seq[e] = pix[(b * L + seq_pixel(k, l, H, W, L)) * pps + c];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cross_merge_nhwc_kernel(const float *__restrict__ seq, float *__restrict__ pix, int64_t pps, int H, int W, int C, int64_t total) {
+    const int L = H * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t bp = e / C;                     // b * L + pixel
+        const int p = (int)(bp % L);
+        const int64_t b = bp / L;
+        const float *sb = seq + b * L * 4 * C + c;
+        const float v0 = sb[((int64_t)pixel_seq(0, p, H, W, L) * 4 + 0) * C], v1 = sb[((int64_t)pixel_seq(1, p, H, W, L) * 4 + 1) * C];
+        const float v2 = sb[((int64_t)pixel_seq(2, p, H, W, L) * 4 + 2) * C], v3 = sb[((int64_t)pixel_seq(3, p, H, W, L) * 4 + 3) * C];
+        pix[bp * pps + c] = ((v0 + v2) + v1) + v3;    // add order of CNN_Mamba.py:552 (= MedMamba.py:476)
+    }
+}
+
+static unsigned grid_for(int64_t total) {
+    const int64_t blocks = (total + 255) / 256;
+    return (unsigned)(blocks < 65536 ? blocks : 65536);
+}
+
+int cross_scan_nhwc_dispatch(const float *pix, int64_t pps, float *seq, int batch, int H, int W, int C, hipStream_t s) {
+    if (!pix || !seq) return MS_ERR_NULL;
+    if (batch < 0 || H <= 0 || W <= 0 || C <= 0 || pps < C || (int64_t)H * W >= (1LL << 30)) return MS_ERR_SHAPE;
+    const int64_t total = (int64_t)batch * H * W * 4 * C;
+    if (total == 0) return MS_OK;
+    hipLaunchKernelGGL(cross_scan_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, pix, pps, seq, H, W, C, total);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int cross_merge_nhwc_dispatch(const float *seq, float *pix, int64_t pps, int batch, int H, int W, int C, hipStream_t s) {
+    if (!pix || !seq) return MS_ERR_NULL;
+    if (batch < 0 || H <= 0 || W <= 0 || C <= 0 || pps < C || (int64_t)H * W >= (1LL << 30)) return MS_ERR_SHAPE;
+    const int64_t total = (int64_t)batch * H * W * C;
+    if (total == 0) return MS_OK;
+    hipLaunchKernelGGL(cross_merge_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, seq, pix, pps, H, W, C, total);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
 }  // namespace ms
