@@ -207,10 +207,10 @@ def test_vfefm_small_matches_cpu_oracle():
     ref.load_state_dict(net.state_dict())
     ssd_oracle.install_ssd(ref)
     net.to(dev()).train(); ref.train()
-    x1, x2 = torch.rand(2, 3, 64, 64), torch.rand(2, 3, 64, 64)
+    x1, x2 = torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64)          # (the CPU oracle side dominates this test's time)
     out_r = ssd_oracle.vfefm_forward_oracle(ref, x1, x2)
     out_d = net(x1.to(dev()), x2.to(dev()))
-    assert tuple(out_d.shape) == (2, 1, 64, 64)
+    assert tuple(out_d.shape) == (1, 1, 64, 64)
     close(out_d, out_r, 2e-3, "fused image")
     crit = FusionLoss()
     lr_ = crit(x1, x2, out_r.clamp(0, 1))[0]
