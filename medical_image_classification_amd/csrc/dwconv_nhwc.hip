@@ -5,8 +5,9 @@
 //       in_proj's output xz is consumed in place);  y : (B, H, W, C) contiguous fp32.
 // One wave = 64 channels x one image row; lanes are channels (256-byte coalesced rows), the 3x3 window slides along W
 // in registers: 3 loads + 9 FMAs per output, every input row is fetched by 3 waves (L2 hits).
-//   bwd: two streaming passes -- (1) dpre = dy * silu'(pre) with pre recomputed, dw[c,k] / dbias[c] accumulated per lane over
-//        the row (one atomic per (row, channel)); (2) dx = conv^T(dpre).  dpre lives in a caller-provided scratch tensor.
+//   bwd: two streaming passes -- (1) dpre = dy * silu'(pre) with pre recomputed (dy = a sum of gradient slabs, see the kernel),
+//        dw[c,k] / dbias[c] accumulated per lane over the rows, combined per workgroup into its slot of a partial-sum table that
+//        a finalize kernel adds up; (2) dx = conv^T(dpre).  dpre and the table live in a caller-provided scratch tensor.
 #include <hip/hip_runtime.h>
 #include "medscan.h"
 
@@ -72,15 +73,11 @@ dwconv_nhwc_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w, con
 
 // Backward, pass 1: dpre = dy * silu'(conv(x) + b) for one image row (same sliding window as the forward: 3 loads
 // per pixel), stored to a scratch tensor; the parameter gradients dw[c, 0..8], dbias[c] are accumulated per lane over the
-// row and added with one atomic per (row, channel).
-#ifndef DW_ROWS
-#define DW_ROWS 2
-#endif
-#ifndef DW_COLS
-#define DW_COLS 4
-#endif
-constexpr int kRowsPerWaveBwd1 = DW_ROWS;      // rows per wave in pass 1; with the 4-wave LDS combine: 8x fewer same-address atomics
-constexpr int kColsBwd1 = DW_COLS;      // columns per trip in pass 1
+// rows and leave the workgroup as one slot of the partial-sum table.
+// pass-1 geometry, measured on the four MedMamba-T stage shapes (tools/bench_dwconv.py): rows per wave 1 / 2 / 4 -> 165 / 168 /
+// 196 us at stage 0 (2: half the partial-sum slots of 1 at the same speed); columns per trip 4 / 8 -> 168 / 167 us
+constexpr int kRowsPerWaveBwd1 = 2;
+constexpr int kColsBwd1 = 4;
 
 // NDIR > 0: the slab count is a compile-time constant, so the 4 x (NDIR + EXTRA) gradient loads of a trip are issued
 // together with the 12 window loads (a run-time slab loop makes each add wait for its own load: measured 330 us instead
@@ -153,11 +150,7 @@ dwconv_nhwc_bwd1_kernel(const T *__restrict__ x, const float *__restrict__ w, co
                     pre = fmaf(k[0], a0, pre); pre = fmaf(k[1], b0, pre); pre = fmaf(k[2], c0, pre);
                     pre = fmaf(k[3], a1, pre); pre = fmaf(k[4], b1, pre); pre = fmaf(k[5], c1, pre);
                     pre = fmaf(k[6], a2, pre); pre = fmaf(k[7], b2, pre); pre = fmaf(k[8], c2, pre);
-                    #ifdef DW_FASTSIG
-                    const float sg = __frcp_rn(1.0f + __expf(-pre));
-#else
                     const float sg = sigm(pre);
-#endif
                     const float dp = g * (sg * (1.0f + pre * (1.0f - sg)));
                     if (cv) po[(int64_t)(w0 + q) * C] = dp;
                     acc[0] = fmaf(dp, a0, acc[0]); acc[1] = fmaf(dp, b0, acc[1]); acc[2] = fmaf(dp, c0, acc[2]);
