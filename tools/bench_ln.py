@@ -16,8 +16,11 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for D, Hh in [(96, 56), (192, 28), (384, 14), (768, 7)]:
-    npix = 64 * Hh * Hh
+SHAPES = [(96, 56, 64), (192, 28, 64), (384, 14, 64), (768, 7, 64)]            # MedMamba-T bs 64
+if len(sys.argv) > 1 and sys.argv[1] == "B":                                      # MedMamba-B 512x512 bs 32
+    SHAPES = [(128, 128, 32), (256, 64, 32), (512, 32, 32), (1024, 16, 32)]
+for D, Hh, bs in SHAPES:
+    npix = bs * Hh * Hh
     y4 = torch.randn(4, npix, D, device=dev); z = torch.randn(npix, D, device=dev).bfloat16()
     gm, bt = torch.randn(D, device=dev), torch.randn(D, device=dev)
     out = torch.empty(npix, D, device=dev, dtype=torch.bfloat16); dout = torch.randn(npix, D, device=dev).bfloat16()
