@@ -77,7 +77,12 @@ typedef enum MsStatus {
                              /* SS2D mode only: the B/C rows (and dB/dC) are addressed through the pixel order of direction
                                 `dir` (0..3) for EVERY group, while u/delta/out keep their own group's order -- the SSD layout
                                 of CNN_Mamba.py:506-519, where the four directions' B/C form one concatenated state vector.
-                                Requires the scalar-decay form (A_dstate_stride == 0). */
+                                Requires the scalar-decay form (A_dstate_stride == 0).
+                                dir == 4 (forward only): ALL four directions in one launch -- dstate = 4 * nd (nd <= 16), state
+                                slice j (states j*nd .. j*nd+nd-1) reads the SAME nd columns of B / C through direction j's
+                                order; the saved states `x` are laid out slice-major, (4, batch, n_chunks, nd, dim), i.e. as
+                                the four `x` tensors of four one-direction launches, which is what the backward launches
+                                (one per direction) then read. */
 
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;

@@ -222,6 +222,25 @@ struct RowIO {
         for (int k = 0; k < NE; ++k)
             r[k] = *reinterpret_cast<const float *>(b + ((in(k) && nk(k) < N && lk(k) < len) ? off[k] : safe));
     }
+    // SS2D mode, "all directions" (MS_SCAN_BC_MAP(4)): the state axis is four slices of `nd` states, slice j read through
+    // direction j's position table (tabs[j]) from the SAME nd columns of the row tensor -- the SSD blocks' concatenation of
+    // the four directions' B / C (CNN_Mamba.py:506-519) without materialising it.
+    __device__ __forceinline__ void fetch_dirs(float (&r)[NE], const float *base, int sl, const int (*tabs)[kCL], int nd, int N,
+                                               int len) const {
+        static_assert(NCONTIG, "fetch_dirs: SS2D mode only");
+        const char *b = reinterpret_cast<const char *>(base);
+        const uint32_t safe = (uint32_t)__mul24(tabs[0][0], sl) * 4u;
+        uint32_t off[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int n = nk(k);
+            const int j = min(n / nd, 3);
+            off[k] = (uint32_t)(n - j * nd + __mul24(tabs[j][lk(k)], sl)) * 4u;
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            r[k] = *reinterpret_cast<const float *>(b + ((in(k) && nk(k) < N && lk(k) < len) ? off[k] : safe));
+    }
     __device__ __forceinline__ void put(float *s, const float (&r)[NE], int N, int len) const {
 #pragma unroll
         for (int k = 0; k < NE; ++k)

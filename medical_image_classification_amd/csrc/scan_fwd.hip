@@ -25,8 +25,10 @@ template <int CW> constexpr int fwd_waves() { return 32 / CW; }
 // SA ("scalar A"): every state of a channel shares one decay rate (A passed with A_dstate_stride == 0 -- the SSD /
 // Mamba-2 form, CNN_Mamba.py:514): a = exp2(delta' * A) is evaluated once per position instead of once per state.
 // BCM ("B/C map", SS2D mode with MS_SCAN_BC_MAP): the B/C rows follow the pixel order of ONE fixed direction for every
-// group, the activations their own group's -- a second per-chunk position table.
-template <int NPL, int CW, int MODE, bool SA = false, bool BCM = false>
+// group, the activations their own group's -- a second per-chunk position table.  BCM == 2 (MS_SCAN_BC_MAP(4)): ALL four
+// directions in one launch -- the state axis is four slices, slice j's rows follow direction j (four tables): the whole
+// concatenated SSD state (CNN_Mamba.py:506-519) in a single pass over u / delta instead of one pass per direction.
+template <int NPL, int CW, int MODE, bool SA = false, int BCM = 0>
 __global__ void __launch_bounds__(64 * fwd_waves<CW>())
 scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, kWF = fwd_waves<CW>();
@@ -39,7 +41,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     __shared__ float sdl_[kWF][kTile];      // delta' tile
     __shared__ float sbias_[kWF][kCW];
     __shared__ int spos_[kWF][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
-    __shared__ int sposb_[BCM ? kWF : 1][2][kCL];   // BCM: the same for the B/C rows' direction
+    __shared__ int sposb_[BCM ? kWF : 1][2][BCM == 2 ? 4 : 1][kCL];   // BCM: the same for the B/C rows' direction(s)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *su = su_[wv], *sdl = sdl_[wv], *sbias = sbias_[wv];
@@ -93,7 +95,8 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
     pm.tab = nullptr; pm.tab_base = 0;
     PosMap pmb = pm;                         // B/C rows: same order as the activations unless BCM
-    if (BCM) pmb.mode = ((p.delta_softplus >> 4) & 7) - 1;
+    if (BCM == 1) pmb.mode = ((p.delta_softplus >> 4) & 7) - 1;
+    const int nd = BCM == 2 ? N / 4 : N;                    // states per direction slice
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = (p.delta_softplus & MS_SCAN_SOFTPLUS) != 0;
@@ -112,13 +115,22 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         if (MODE == kModeSS2D) {
             pm.fill_table(spos[ch & 1], l0, lane);
-            if (BCM) pmb.fill_table(sposb_[wv][ch & 1], l0, lane); else pmb = pm;
+            if (BCM == 1) pmb.fill_table(sposb_[wv][ch & 1][0], l0, lane);
+            else if (BCM == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { PosMap pj = pm; pj.mode = j; pj.fill_table(sposb_[wv][ch & 1][j], l0, lane); }
+            } else pmb = pm;
             wave_sync();
         }
         tile.fetch(ru, ub, u_sd, u_sl, l0, pm, nvalid, len);
         tile.fetch(rd, db, dl_sd, dl_sl, l0, pm, nvalid, len);
-        rows.fetch(rB, Bb, B_sn, B_sl, l0, pmb, N, len);
-        rows.fetch(rC, Cb, C_sn, C_sl, l0, pmb, N, len);
+        if constexpr (BCM == 2) {
+            rows.fetch_dirs(rB, Bb, B_sl, sposb_[wv][ch & 1], nd, N, len);
+            rows.fetch_dirs(rC, Cb, C_sl, sposb_[wv][ch & 1], nd, N, len);
+        } else {
+            rows.fetch(rB, Bb, B_sn, B_sl, l0, pmb, N, len);
+            rows.fetch(rC, Cb, C_sn, C_sl, l0, pmb, N, len);
+        }
     };
     fetch(0);
     wave_sync();                                           // sbias visible
@@ -164,7 +176,10 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 const int n = sg * NPL + i;
-                if (n < N) p.x[(((int64_t)b * n_chunks + ch) * N + n) * p.dim + d] = h[i];
+                if (BCM == 2) {         // slice-major checkpoints: slice j is what a one-direction backward launch reads
+                    const int j = n / nd;
+                    if (n < N) p.x[((((int64_t)j * p.batch + b) * n_chunks + ch) * nd + (n - j * nd)) * p.dim + d] = h[i];
+                } else if (n < N) p.x[(((int64_t)b * n_chunks + ch) * N + n) * p.dim + d] = h[i];
             }
         }
         wave_sync();
@@ -212,10 +227,12 @@ static int launch_fwd(const MsScanParams &p, int n_chunks, hipStream_t stream) {
     if (p.map_h > 0 && !small) return MS_ERR_STRIDE;
     const bool sa = p.A_dstate_stride == 0 && p.dstate > 1;     // scalar decay per channel (SSD form): channel-last variant only
     const int bc_dir = ((p.delta_softplus >> 4) & 7) - 1;       // MS_SCAN_BC_MAP
-    if (bc_dir >= 0 && (p.map_h <= 0 || !sa || bc_dir > 3)) return MS_ERR_SHAPE;
+    if (bc_dir >= 0 && (p.map_h <= 0 || !sa || bc_dir > 4)) return MS_ERR_SHAPE;
+    if (bc_dir == 4 && (p.dstate % 4 != 0 || p.dstate / 4 > 16 || (p.delta_softplus & MS_SCAN_ACCUMULATE))) return MS_ERR_SHAPE;
     switch (pick_mode(lcontig, dcontig, small, p.map_h)) {
         case kModeSS2D:
-            if (bc_dir >= 0) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D, true, true>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
+            if (bc_dir == 4) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D, true, 2>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
+            else if (bc_dir >= 0) hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D, true, 1>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
             else hipLaunchKernelGGL((scan_fwd_kernel<NPL, CW, kModeSS2D>), grid, dim3(64 * kWF), 0, stream, p, n_chunks, ncb);
             break;
         case kModeCL:
@@ -266,6 +283,11 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
             case 2: return launch_fwd<2, 8>(p, n_chunks, stream);
         }
     }
+    // all-direction SSD launch (64 states = 4 x 16): 8-channel waves x 8 states per lane while 16-channel waves would
+    // leave the chip under-filled (same rule as use_cw8 applies to 16 states)
+    if ((((p.delta_softplus >> 4) & 7) - 1) == 4 && p.dstate == 64 &&
+        (int64_t)p.batch * p.n_groups * ((p.dim / p.n_groups + 15) / 16) < 2048)
+        return launch_fwd<8, 8>(p, n_chunks, stream);
     switch (pick_npl(p.dstate, 4)) {
         case 1: return launch_fwd<1, 16>(p, n_chunks, stream);
         case 2: return launch_fwd<2, 16>(p, n_chunks, stream);

@@ -14,6 +14,7 @@ pointwise per pixel, so here every tensor stays in PIXEL order, channel-last:
 so cross-scan and cross-merge cost no memory traffic at all, and nothing is ever transposed.
 """
 import ctypes
+import os
 
 import torch
 
@@ -480,13 +481,22 @@ class _SSDScanMerge(torch.autograd.Function):
         x_state = torch.empty((len(slices), B, n_chunks, _SSD_SLICE, 4 * Ds), device=xc.device, dtype=torch.float32)
         stream = _lib.current_stream_ptr(xc.device)
         with _lib.on_device(xc.device):
-            for i, (j, s0, ns) in enumerate(slices):
+            if N == _SSD_SLICE and SSD_ONE_LAUNCH_FWD:
+                # all four directions' B/C slices in ONE launch (MS_SCAN_BC_MAP(4)): one pass over u / delta / y instead of
+                # four, the saved states in the slice-major layout the four backward launches read
                 P = MsScanParams()
-                _ssd_params(P, xc, delta, A_col, D_full if i == 0 else None, bias_full, y4, x_state[i], B, L, H, W, Ds, N, conv,
-                            j, s0, ns, i > 0)
-                rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * Ds, L, ns, 4, False), xc.device,
+                _ssd_params(P, xc, delta, A_col, D_full, bias_full, y4, x_state, B, L, H, W, Ds, N, conv, 4, 0, 4 * N, False)
+                rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * Ds, L, 4 * N, 4, False), xc.device,
                                   lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
-                _lib.check(rc, "ms_selective_scan_fwd[ssd]")
+                _lib.check(rc, "ms_selective_scan_fwd[ssd, all directions]")
+            else:
+                for i, (j, s0, ns) in enumerate(slices):
+                    P = MsScanParams()
+                    _ssd_params(P, xc, delta, A_col, D_full if i == 0 else None, bias_full, y4, x_state[i], B, L, H, W, Ds, N, conv,
+                                j, s0, ns, i > 0)
+                    rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * Ds, L, ns, 4, False), xc.device,
+                                      lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
+                    _lib.check(rc, "ms_selective_scan_fwd[ssd]")
         ctx.save_for_backward(xc, delta, A_col, D_full, bias_full, x_state)
         ctx.geom = (H, W, Ds, N, nheads, headdim, bool(d_has_hdim), As.shape, Dsv.shape, dt_bias.shape)
         return ((y4[0] + y4[2]) + y4[1]) + y4[3]
@@ -533,7 +543,8 @@ class _SSDScanMerge(torch.autograd.Function):
         return dxc, dAs, dDs, dbt, None, None, None, None, None, None, None
 
 
-_SSD_SLICE = 16      # states per launch (the scan kernels keep <= 16 states of a channel in registers)
+_SSD_SLICE = 16      # states per backward launch (the backward kernels keep <= 16 states of a channel in registers)
+SSD_ONE_LAUNCH_FWD = os.environ.get("MEDSCAN_SSD_ONE_LAUNCH_FWD", "1") == "1"
 
 
 def _ssd_slices(N):

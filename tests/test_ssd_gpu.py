@@ -391,3 +391,32 @@ def test_channel_last_cross_scan_merge_kernels(cfg):
     gm = torch.randn(m.shape, generator=gen).to(dev())
     m.backward(gm)
     assert torch.equal(y.grad, gm[:, idx.t().reshape(-1)].view(B, L, 4, -1))
+
+
+@pytest.mark.parametrize("cfg", [(64, 64, 9, 7, 2), (128, 64, 14, 14, 3), (32, 16, 5, 12, 1), (64, 32, 40, 3, 2)])
+def test_ssd_all_direction_forward_launch_matches_four_launches(cfg, monkeypatch):
+    """MS_SCAN_BC_MAP(4): the 64-state SSD forward (4 directions x 16 states) in ONE launch == four one-direction launches that
+    add up, and the slice-major saved states it writes drive the same backward: output and every gradient."""
+    from medical_image_classification_amd import cnn_mamba as cm
+    from medical_image_classification_amd import ss2d_fused as sf
+    d_model, headdim, H, W, B = cfg
+    torch.manual_seed(H * W)
+    m = cm.SS2D_with_SSD(d_model=d_model, d_state=16, headdim=headdim).to(dev())
+    with torch.no_grad():
+        m.Ds.add_(torch.randn_like(m.Ds) * 0.3); m.A_logs.add_(torch.randn_like(m.A_logs) * 0.3); m.dt_bias.add_(torch.randn_like(m.dt_bias))
+    monkeypatch.setattr(cm, "SSD_CHUNKED_MIN_STATE", 0)
+    u = torch.randn(B, H, W, d_model, device=dev())
+    g = torch.randn(B, H, W, d_model, device=dev())
+    res = []
+    for one in (True, False):
+        monkeypatch.setattr(sf, "SSD_ONE_LAUNCH_FWD", one)
+        m.zero_grad(set_to_none=True)
+        ui = u.clone().requires_grad_()
+        y = m(ui)
+        y.backward(g)
+        res.append((y.detach(), ui.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (y1, du1, p1), (y0, du0, p0) = res
+    close(y1, y0, 1e-5, "y")
+    close(du1, du0, 1e-4, "du")
+    for k in p0:
+        close(p1[k], p0[k], 1e-4, k)
