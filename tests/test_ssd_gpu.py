@@ -393,7 +393,8 @@ def test_channel_last_cross_scan_merge_kernels(cfg):
     assert torch.equal(y.grad, gm[:, idx.t().reshape(-1)].view(B, L, 4, -1))
 
 
-@pytest.mark.parametrize("cfg", [(64, 64, 9, 7, 2), (128, 64, 14, 14, 3), (32, 16, 5, 12, 1), (64, 32, 40, 3, 2)])
+@pytest.mark.parametrize("cfg", [(64, 64, 9, 7, 2), (128, 64, 14, 14, 3), (32, 16, 5, 12, 1), (64, 32, 40, 3, 2),
+                                 (512, 64, 3, 5, 8)])          # the last one: enough waves for the 16-channel / 16-states-per-lane variant
 def test_ssd_all_direction_forward_launch_matches_four_launches(cfg, monkeypatch):
     """MS_SCAN_BC_MAP(4): the 64-state SSD forward (4 directions x 16 states) in ONE launch == four one-direction launches that
     add up, and the slice-major saved states it writes drive the same backward: output and every gradient."""
