@@ -234,7 +234,7 @@ def test_fused_core_matches_layout_faithful_path(cfg, monkeypatch):
             assert float((gf[k] - gu[k]).abs().max()) <= 2e-3 * sc(gu[k]), k
 
 
-@pytest.mark.parametrize("cfg", [(16, 6, 9, 2), (96, 28, 28, 2), (12, 5, 7, 3)])
+@pytest.mark.parametrize("cfg", [(16, 6, 9, 2), (96, 28, 28, 2), (12, 5, 7, 3), (48, 56, 56, 64)])     # last: BASELINE stage-0 size
 def test_ss2d_single_node_bf16_autocast_matches_per_op_nodes(cfg, monkeypatch):
     """Under bf16 autocast the one-node SS2D inner path (gradients handed kernel to kernel, dx/dz written as bf16 into one
     xz gradient) == the per-op autograd path to bf16 rounding."""
