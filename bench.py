@@ -176,13 +176,15 @@ def main():
         torch.cuda.synchronize()
 
     log(f"model on {device}, world {world}; warm-up {args.warmup} steps")
-    from medical_image_classification_amd.medmamba import set_branch_streams
+    from medical_image_classification_amd import medmamba as _mm
     for i in range(args.warmup):
         train_step(model, opt, lossf, images, labels, ac)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
         if i == 0:
-            set_branch_streams(True)           # only if MEDSCAN_BRANCH_STREAMS=late|1 asks for two-stream blocks (opt-in)
+            # two-stream blocks: decided per process by measurement (MEDSCAN_BRANCH_STREAMS=auto, the default): 15 extra
+            # untimed steps, every rank runs the same number of them (they contain the gradient all-reduce)
+            _mm.autotune_branch_streams(lambda: train_step(model, opt, lossf, images, labels, ac), device, log=log)
     barrier()
     ssi.TIMER.enabled = True
     t0 = time.perf_counter()

@@ -16,7 +16,7 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
-from .medmamba import set_branch_streams
+from .medmamba import BranchStreamTuner
 from .train import build_model, make_adam, synthetic_batch, train_step
 
 
@@ -157,14 +157,16 @@ def main(argv=None):
     ddp_net = wrap_ddp(net, distributed, local_rank)
     loss_function = nn.CrossEntropyLoss()
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    tuner = BranchStreamTuner(device)           # two-stream blocks: measured per process on the first steps (rank-local)
     for epoch in range(start_epoch, args.epochs):
         ddp_net.train()
         running = 0.0
         for _ in range(args.steps_per_epoch):
             images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
-            running += train_step(ddp_net, optimizer, loss_function, images, labels,
-                                  torch.bfloat16 if args.bf16 else None).item()
-            set_branch_streams(True)            # opt-in (MEDSCAN_BRANCH_STREAMS=late): two-stream blocks after the first step
+            tuner.begin()
+            loss = train_step(ddp_net, optimizer, loss_function, images, labels, torch.bfloat16 if args.bf16 else None)
+            tuner.end()
+            running += loss.item()
         if hasattr(ddp_net, "sync_buffers"):
             ddp_net.sync_buffers()              # rank 0's BatchNorm statistics everywhere before they are saved / evaluated
         if rank == 0:

@@ -36,23 +36,113 @@ CONV_CHANNELS_LAST = os.environ.get("MEDSCAN_CONV_CL", "1") == "1"
 BLOCK_FUSED = os.environ.get("MEDSCAN_BLOCK_FUSED", "1") == "1"
 # SS2D: conv -> x_proj -> dt_proj -> scan -> norm/gate as one autograd node (ss2d_fused._SS2DInner); 0 = one node per op
 SS2D_NODE = os.environ.get("MEDSCAN_SS2D_NODE", "1") == "1"
-# SS_Conv_SSM: optionally run the conv branch on a side HIP stream, concurrently with the LayerNorm + SS2D branch (the
-# branches are independent until the tail).  OPT-IN: measured on MedMamba-T bs 64 it takes the step from 27.0 ms to
-# 24-25 ms in most processes but to 28-31 ms in others (same build, same box -- which hardware queue the side stream lands
-# on and how the per-stream allocator pools settle is not under our control), so the default stays single-stream.
-#   MEDSCAN_BRANCH_STREAMS=1     two streams from the first step
-#   MEDSCAN_BRANCH_STREAMS=late  the training drivers switch it on after their first step (set_branch_streams), once
-#                                MIOpen's find pass and the main-stream allocator pool are settled -- the better variant
-BRANCH_STREAMS = os.environ.get("MEDSCAN_BRANCH_STREAMS", "") == "1"
+# SS_Conv_SSM: the conv branch can run on a side HIP stream, concurrently with the LayerNorm + SS2D branch (the branches
+# are independent until the tail).  Whether that pays is decided per PROCESS: on MedMamba-T bs 64 it takes the step from
+# 25.0 ms to 21.7-24.8 ms in most processes, but a process can also land in a mode where it costs time (27-31 ms measured in
+# earlier builds; which hardware queue the side stream lands on and how the per-stream allocator pools settle is not
+# under our control).  So the training drivers MEASURE it at start-up and keep what is faster in this process:
+#   MEDSCAN_BRANCH_STREAMS=auto  (default) time a few steps each way after the first step (BranchStreamTuner /
+#                                autotune_branch_streams), keep two streams only if they win
+#   MEDSCAN_BRANCH_STREAMS=0     single stream          =1  two streams from the first step
+#   MEDSCAN_BRANCH_STREAMS=late  two streams from the second step on, unconditionally
+_BRANCH_MODE = os.environ.get("MEDSCAN_BRANCH_STREAMS", "auto")
+BRANCH_STREAMS = _BRANCH_MODE == "1"
 _SIDE_STREAMS = {}
 
 
 def set_branch_streams(flag=True):
     """Called by the training drivers after their first step: turns the two-stream blocks on when the user asked for
-    them with MEDSCAN_BRANCH_STREAMS=late (or =1); a no-op otherwise."""
+    them unconditionally (MEDSCAN_BRANCH_STREAMS=late or =1); a no-op otherwise."""
     global BRANCH_STREAMS
-    BRANCH_STREAMS = bool(flag) and os.environ.get("MEDSCAN_BRANCH_STREAMS", "") in ("1", "late")
+    BRANCH_STREAMS = bool(flag) and _BRANCH_MODE in ("1", "late")
     return BRANCH_STREAMS
+
+
+def autotune_branch_streams(step, device, steps=5, prime=4, candidates=3, log=None):
+    """MEDSCAN_BRANCH_STREAMS=auto: `step()` runs one training step.  `steps` timed single-stream steps, then `prime`
+    untimed two-stream steps (the side stream's allocator pool and MIOpen handles take a few steps to settle) and `steps`
+    timed ones; two-stream blocks stay on only if they are at least 1.5 % faster in this process.  Other settings: behaves
+    like set_branch_streams(True).  Returns the choice."""
+    global BRANCH_STREAMS
+    if _BRANCH_MODE != "auto":
+        return set_branch_streams(True)
+    import time
+
+    def timed(n):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / n
+
+    BRANCH_STREAMS = False
+    step()
+    single = timed(steps)
+    BRANCH_STREAMS = True
+    best, best_stream = None, None
+    for attempt in range(candidates):                    # a side stream that does not pay may just sit on an unlucky queue
+        if attempt > 0:
+            _SIDE_STREAMS.pop(device.index, None)        # _side_stream() probes a fresh one
+        for _ in range(prime):
+            step()
+        two = timed(steps)
+        if log is not None:
+            log(f"two-stream blocks, side stream {attempt}: {1e3 * two:.2f} ms/step vs {1e3 * single:.2f} single-stream")
+        if best is None or two < best:
+            best, best_stream = two, _SIDE_STREAMS.get(device.index)
+        if two < 0.94 * single:
+            break
+    if best_stream is not None:
+        _SIDE_STREAMS[device.index] = best_stream
+    BRANCH_STREAMS = best < 0.985 * single
+    if log is not None:
+        log(f"two-stream blocks: {'on' if BRANCH_STREAMS else 'off'} in this process")
+    return BRANCH_STREAMS
+
+
+class BranchStreamTuner:
+    """The same decision inside a training loop, on the loop's own steps (no extra work): wrap each step in begin() / end().
+    Step 0 is skipped (first-use costs), one single-stream priming step and 5 timed ones, 4 two-stream priming steps and 5
+    timed ones; after that the choice is fixed and begin() / end() cost nothing."""
+
+    _PLAN = [None, False] + [False] * 5 + [True] * 4 + [True] * 5     # mode of step i; None = leave as is
+    _TIMED = [False, False] + [True] * 5 + [False] * 4 + [True] * 5
+
+    def __init__(self, device):
+        self.device, self.i, self.spent, self.t0 = device, 0, {False: 0.0, True: 0.0}, None
+        self.auto = _BRANCH_MODE == "auto"
+        self.active = self.auto
+        self.calls = 0
+
+    def begin(self):
+        global BRANCH_STREAMS
+        self.calls += 1
+        if not self.active:
+            if not self.auto and self.calls == 2:        # =late / =1: on from the second step, unconditionally
+                set_branch_streams(True)
+            return
+        import time
+        mode = self._PLAN[self.i]
+        if mode is not None:
+            BRANCH_STREAMS = mode
+            if self._TIMED[self.i]:
+                torch.cuda.synchronize(self.device)
+                self.t0 = time.perf_counter()
+
+    def end(self):
+        global BRANCH_STREAMS
+        if not self.active:
+            return
+        import time
+        if self.t0 is not None:
+            torch.cuda.synchronize(self.device)
+            self.spent[self._PLAN[self.i]] += time.perf_counter() - self.t0
+            self.t0 = None
+        self.i += 1
+        if self.i == len(self._PLAN):
+            BRANCH_STREAMS = self.spent[True] < 0.985 * self.spent[False]
+            self.active = False
 
 
 def _side_stream(device):
@@ -84,7 +174,7 @@ def _side_stream(device):
             s = cand
             break
     _SIDE_STREAMS[device.index] = s if s is not None else keep[0]
-    _SIDE_STREAMS[("probed", device.index)] = keep
+    _SIDE_STREAMS.setdefault(("probed", device.index), []).extend(keep)      # (kept alive: the pool then hands out new ones)
     return _SIDE_STREAMS[device.index]
 
 

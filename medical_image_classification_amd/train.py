@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .medmamba import VSSM as medmamba
-from .medmamba import set_branch_streams
+from .medmamba import BranchStreamTuner
 
 
 def synthetic_batch(batch_size, num_classes, res=224, device="cuda", generator=None):
@@ -76,14 +76,16 @@ def main(argv=None):
     optimizer = make_adam(net.parameters(), lr=0.0001)
     gen = torch.Generator(device=device).manual_seed(0)
     best_acc = 0.0
+    tuner = BranchStreamTuner(device)           # two-stream blocks: measured on the first steps, kept only if faster here
     for epoch in range(args.epochs):
         net.train()
         running_loss, t0 = 0.0, time.time()
         for step in range(args.steps_per_epoch):
             images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
+            tuner.begin()
             loss = train_step(net, optimizer, loss_function, images, labels, torch.bfloat16 if args.bf16 else None)
+            tuner.end()
             running_loss += loss.item()
-            set_branch_streams(True)            # opt-in (MEDSCAN_BRANCH_STREAMS=late): two-stream blocks after the first step
         dt = time.time() - t0
         net.eval()
         acc = 0

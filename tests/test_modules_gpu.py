@@ -656,3 +656,50 @@ def test_vssm_eval_mode_inference_vs_oracle(bf16):
     for m in net.modules():                                 # eval mode leaves the buffers alone
         if isinstance(m, torch.nn.BatchNorm2d):
             assert int(m.num_batches_tracked) == 0
+
+
+def test_branch_stream_tuner_and_two_stream_training_trajectory():
+    """(1) BranchStreamTuner walks its plan on a loop's own steps and ends with a decision; (2) a VSSM trained for a few steps
+    with two-stream blocks follows the single-stream trajectory (losses and parameters to rounding)."""
+    from medical_image_classification_amd import medmamba as mm
+    from medical_image_classification_amd.train import make_adam, train_step
+    def run(mode, tuner_on):
+        torch.manual_seed(9)
+        net = mm.VSSM(depths=[1, 1], dims=[32, 64], num_classes=4, drop_path_rate=0.0).to(dev()).train()
+        opt = make_adam(net.parameters(), lr=1e-3)
+        g = torch.Generator(device=dev()).manual_seed(2)
+        x = torch.randn(4, 3, 64, 64, device=dev(), generator=g)
+        y = torch.randint(0, 4, (4,), device=dev(), generator=g)
+        tuner = mm.BranchStreamTuner(dev())
+        tuner.active = tuner_on
+        losses = []
+        for _ in range(len(mm.BranchStreamTuner._PLAN) + 1):
+            if tuner_on:
+                tuner.begin()
+            else:
+                mm.BRANCH_STREAMS = mode
+            losses.append(train_step(net, opt, torch.nn.CrossEntropyLoss(), x, y, torch.bfloat16).item())
+            if tuner_on:
+                tuner.end()
+        return net, losses, tuner
+    try:
+        n0, l0, _ = run(False, False)
+        n1, l1, _ = run(True, False)
+        n2, l2, tuner = run(None, True)
+        assert not tuner.active and tuner.i == len(mm.BranchStreamTuner._PLAN) and isinstance(mm.BRANCH_STREAMS, bool)
+        assert tuner.spent[False] > 0 and tuner.spent[True] > 0
+        # the start-up version bench.py uses (extra steps, up to `candidates` side streams)
+        torch.manual_seed(9)
+        net = mm.VSSM(depths=[1, 1], dims=[32, 64], num_classes=4, drop_path_rate=0.0).to(dev()).train()
+        opt = make_adam(net.parameters(), lr=1e-3)
+        x = torch.randn(4, 3, 64, 64, device=dev()); y = torch.randint(0, 4, (4,), device=dev())
+        lines = []
+        choice = mm.autotune_branch_streams(lambda: train_step(net, opt, torch.nn.CrossEntropyLoss(), x, y, torch.bfloat16), dev(),
+                                            steps=2, prime=1, candidates=2, log=lines.append)
+        assert isinstance(choice, bool) and mm.BRANCH_STREAMS == choice and lines and "process" in lines[-1]
+    finally:
+        mm.BRANCH_STREAMS = False
+    for la, lb in ((l0, l1), (l0, l2)):
+        assert all(abs(a - b) <= 5e-3 * max(1.0, abs(a)) for a, b in zip(la, lb)), (la, lb)
+    for (k, p), (_, q) in zip(n0.named_parameters(), n1.named_parameters()):
+        assert float((p - q).abs().max()) <= 2e-2 * max(1e-2, float(p.abs().max())), k
