@@ -182,8 +182,8 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
         if i == 0:
-            # two-stream blocks: decided per process by measurement (MEDSCAN_BRANCH_STREAMS=auto, the default): 15 extra
-            # untimed steps, every rank runs the same number of them (they contain the gradient all-reduce)
+            # two-stream blocks (opt-in, MEDSCAN_BRANCH_STREAMS=auto): decided per process by measurement -- 15+ extra untimed
+            # steps, every rank runs the same number of them (they contain the gradient all-reduce); a no-op by default
             _mm.autotune_branch_streams(lambda: train_step(model, opt, lossf, images, labels, ac), device, log=log)
     barrier()
     ssi.TIMER.enabled = True

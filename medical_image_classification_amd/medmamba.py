@@ -38,14 +38,16 @@ BLOCK_FUSED = os.environ.get("MEDSCAN_BLOCK_FUSED", "1") == "1"
 SS2D_NODE = os.environ.get("MEDSCAN_SS2D_NODE", "1") == "1"
 # SS_Conv_SSM: the conv branch can run on a side HIP stream, concurrently with the LayerNorm + SS2D branch (the branches
 # are independent until the tail).  Whether that pays is decided per PROCESS: on MedMamba-T bs 64 it takes the step from
-# 25.0 ms to 21.7-24.8 ms in most processes, but a process can also land in a mode where it costs time (27-31 ms measured in
-# earlier builds; which hardware queue the side stream lands on and how the per-stream allocator pools settle is not
-# under our control).  So the training drivers MEASURE it at start-up and keep what is faster in this process:
-#   MEDSCAN_BRANCH_STREAMS=auto  (default) time a few steps each way after the first step (BranchStreamTuner /
+# 25.0 ms to 21.8-24.6 ms in most processes, but a process can also land in a mode where it costs time (27-32 ms; which
+# hardware queue the side stream lands on and how the two kernel streams interleave is not under our control).  With
+# `auto` the training drivers MEASURE it at start-up and keep what is faster in this process (mean 22.8 ms over 8
+# processes, never worse than single-stream).  The default stays single-stream: run-to-run reproducible step times, and
+# per-kernel durations (the roofline figures of bench.py) that are not stretched by a second stream sharing the CUs.
+#   MEDSCAN_BRANCH_STREAMS=0     (default) single stream
+#   MEDSCAN_BRANCH_STREAMS=auto  time a few steps each way after the first step (BranchStreamTuner /
 #                                autotune_branch_streams), keep two streams only if they win
-#   MEDSCAN_BRANCH_STREAMS=0     single stream          =1  two streams from the first step
-#   MEDSCAN_BRANCH_STREAMS=late  two streams from the second step on, unconditionally
-_BRANCH_MODE = os.environ.get("MEDSCAN_BRANCH_STREAMS", "auto")
+#   MEDSCAN_BRANCH_STREAMS=1     two streams from the first step      =late  from the second step on, unconditionally
+_BRANCH_MODE = os.environ.get("MEDSCAN_BRANCH_STREAMS", "0")
 BRANCH_STREAMS = _BRANCH_MODE == "1"
 _SIDE_STREAMS = {}
 
