@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 4
+#define MEDSCAN_ABI_VERSION 5
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -84,6 +84,15 @@ typedef enum MsStatus {
                                 the four `x` tensors of four one-direction launches, which is what the backward launches
                                 (one per direction) then read. */
 
+#define MS_SCAN_DT_FUSED 128  /* SS2D mode only: `delta` is NOT read; the kernels form delta[l, d] = sum_r dt_x[l, r] * dt_w[d, r]
+                                (the `dt_projs` einsum, MedMamba.py:400,403-405) while they stage a tile, then add delta_bias
+                                and apply softplus as usual.  dt_x: the dt_rank leading columns of the x_proj rows, addressed
+                                with B's batch / group / l strides (unit stride along r); dt_w (dim, dt_rank) contiguous
+                                (= dt_projs_weight (4, D, R) flattened); dt_rank <= 32; d_state == 16.  Backward: `ddelta`
+                                is NOT written; ddt_x (same addressing as dB, ACCUMULATED with atomics -- zero it first, it is
+                                normally the dts columns of the projection-row gradient whose B | C columns are dB | dC) and
+                                ddt_w (dim, dt_rank) (ACCUMULATED) receive the gradients of the projection instead. */
+
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;
     int32_t delta_softplus;                 /* flags: MS_SCAN_SOFTPLUS | MS_SCAN_A_IS_LOG (historically a bool: 1 = softplus) */
@@ -97,6 +106,8 @@ typedef struct MsScanParams {
     const float *u, *delta, *A, *B, *C, *D, *delta_bias;
     float *out;
     float *x;
+    const float *dt_x, *dt_w;               /* MS_SCAN_DT_FUSED operands (else ignored) */
+    int32_t dt_rank, reserved0;
 } MsScanParams;
 
 /*
@@ -115,6 +126,7 @@ typedef struct MsScanBwdParams {
     int64_t dC_batch_stride, dC_group_stride, dC_dstate_stride, dC_l_stride;
     const float *dout;
     float *du, *ddelta, *dA, *dB, *dC, *dD, *ddelta_bias;
+    float *ddt_x, *ddt_w;                   /* MS_SCAN_DT_FUSED gradients (else ignored) */
 } MsScanBwdParams;
 
 /* replaces selective_scan_cuda.fwd  (selective_scan.cpp:226-336 -> selective_scan_fwd_kernel.cuh:67-303) */

@@ -28,7 +28,8 @@ class MsScanParams(ctypes.Structure):
             "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_dstate_stride", "B_l_stride",
             "C_batch_stride", "C_group_stride", "C_dstate_stride", "C_l_stride")]
-        + [(n, c_vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "out", "x")]
+        + [(n, c_vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "out", "x", "dt_x", "dt_w")]
+        + [(n, c_i32) for n in ("dt_rank", "reserved0")]
     )
 
 
@@ -42,7 +43,7 @@ class MsScanBwdParams(ctypes.Structure):
             "ddelta_batch_stride", "ddelta_group_stride", "ddelta_d_stride", "ddelta_l_stride",
             "dB_batch_stride", "dB_group_stride", "dB_dstate_stride", "dB_l_stride",
             "dC_batch_stride", "dC_group_stride", "dC_dstate_stride", "dC_l_stride")]
-        + [(n, c_vp) for n in ("dout", "du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias")]
+        + [(n, c_vp) for n in ("dout", "du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "ddt_x", "ddt_w")]
     )
 
 
@@ -51,7 +52,7 @@ EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks",
            "ms_dwconv3x3_silu_nhwc_bwd", "ms_dwconv3x3_silu_nhwc_bwd_scratch_floats", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_bwd", "ms_bn_relu_nhwc_fwd",
            "ms_bn_relu_nhwc_bwd", "ms_bn_scratch_floats", "ms_ssd_chunk_carry", "ms_rms_gate_fwd", "ms_rms_gate_bwd", "ms_spin", "ms_abi_version", "ms_status_string")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

@@ -426,6 +426,7 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
     int rc = validate_scan(p);
     if (rc != MS_OK) return rc;
     if (!q.dout || !q.du || !q.ddelta || !q.dA || !q.dB || !q.dC) return MS_ERR_NULL;
+    if (p.delta_softplus & MS_SCAN_DT_FUSED) return MS_ERR_UNSUPPORTED;     // forward-only this build
     if (!act_strides_ok(q.dout_d_stride, q.dout_l_stride, p.seqlen) || !act_strides_ok(q.du_d_stride, q.du_l_stride, p.seqlen) ||
         !act_strides_ok(q.ddelta_d_stride, q.ddelta_l_stride, p.seqlen) ||
         !act_strides_ok(q.dB_dstate_stride * 4, q.dB_l_stride, p.seqlen) || !act_strides_ok(q.dC_dstate_stride * 4, q.dC_l_stride, p.seqlen))

@@ -26,6 +26,20 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Packed fp32: on gfx950 v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 issue in the 4 cycles of their scalar forms and do two
+// lanes' worth of work (measured, tools/microbench/valu_rate.hip: v_fma_f32 4.3 cycles per wave-instruction per SIMD,
+// v_pk_fma_f32 4.4, v_exp_f32 8.2) -- the kernels are VALU-issue bound, so a lane's states are kept as explicit PAIRS
+// (ext_vector_type(2) in an aligned register pair; a scalar operand is broadcast with op_sel, no v_mov).  The SLP
+// vectorizer stays off (-fno-slp-vectorize): pairs it forms from unrelated scalars need repacking moves.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f exp2_pk(v2f x) { return (v2f){exp2_fast(x.x), exp2_fast(x.y)}; }
+// states per lane padded to whole pairs, and the column of state n in the [position][column] B/C row tiles
+// (lane group sg owns columns sg*NPLp .. sg*NPLp + NPL - 1; an odd NPL leaves one always-zero pad column per group)
+template <int NPL> constexpr int npl_padded() { return (NPL + 1) / 2 * 2; }
+template <int NPL> __device__ __forceinline__ int state_col(int n) { return NPL % 2 == 0 ? n : (n / NPL) * npl_padded<NPL>() + n % NPL; }
+
 // softplus with the reference's definition, x <= 20 ? log1p(exp(x)) : x
 // (selective_scan_fwd_kernel.cuh:153-156; F.softplus threshold 20 in selective_scan_interface.py:112-113),
 // evaluated with the hardware exp2/log2 and Kahan's compensated log1p: log1p(e) = log(1+e) * e / ((1+e) - 1).
@@ -245,6 +259,14 @@ struct RowIO {
 #pragma unroll
         for (int k = 0; k < NE; ++k)
             if (in(k)) s[nk(k) * kRowPitch + lk(k)] = (nk(k) < N && lk(k) < len) ? r[k] : 0.0f;
+    }
+    // [position][state column] layout (row pitch RP floats): a lane's state PAIR of one position is one ds_read_b64
+    // (four states one ds_read_b128); the pad columns of an odd NPL are zeroed once by the kernel
+    template <int NPL, int RP>
+    __device__ __forceinline__ void put_t(float *s, const float (&r)[NE], int N, int len) const {
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (in(k)) s[lk(k) * RP + state_col<NPL>(nk(k))] = (nk(k) < N && lk(k) < len) ? r[k] : 0.0f;
     }
 };
 

@@ -32,19 +32,23 @@ template <int NPL, int CW, int MODE, bool SA = false, int BCM = 0>
 __global__ void __launch_bounds__(64 * fwd_waves<CW>())
 scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     constexpr int SG = 64 / CW, NP = SG * NPL, kWF = fwd_waves<CW>();
+    constexpr int NPLp = npl_padded<NPL>(), NP2 = NPLp / 2;     // states per lane as NP2 packed pairs
+    constexpr int RP = SG * NPLp + 4;                           // row pitch (floats) of the [position][state column] B/C tiles
     using Tile = TileIO<MODE, CW>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     using Rows = RowIO<MODE, NP, fwd_waves<CW>()>;
-    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];          // B / C rows of the chunk: one copy per workgroup
-    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
-    __shared__ float su_[kWF][kTile];       // u tile, overwritten in place by the out tile
-    __shared__ float sdl_[kWF][kTile];      // delta' tile
+    __shared__ __attribute__((aligned(16))) float sB[kCL * RP];       // B / C rows of the chunk: one copy per workgroup
+    __shared__ __attribute__((aligned(16))) float sC[kCL * RP];
+    __shared__ __attribute__((aligned(8))) v2f sdd_[kWF][kTile];     // {delta', delta' * u} per (position, channel)
+    __shared__ float so_[kWF][kTile];        // out tile (the state-group owners write y; the store adds D * u)
     __shared__ float sbias_[kWF][kCW];
+    __shared__ float sDv_[kWF][kCW];
     __shared__ int spos_[kWF][2][kCL];      // SS2D mode: pixel positions of the chunk being computed / being prefetched
     __shared__ int sposb_[BCM ? kWF : 1][2][BCM == 2 ? 4 : 1][kCL];   // BCM: the same for the B/C rows' direction(s)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *su = su_[wv], *sdl = sdl_[wv], *sbias = sbias_[wv];
+    v2f *sdd = sdd_[wv];
+    float *so = so_[wv], *sbias = sbias_[wv], *sDv = sDv_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
 
@@ -73,17 +77,24 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const bool active = c < nvalid;
     const int d = d0 + (active ? c : max(nvalid, 1) - 1);
 
-    float A2[NPL], h[NPL];
+    v2f A2[NP2], h[NP2];
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
+    for (int i = 0; i < NPLp; ++i) {
         const int n = sg * NPL + i;
-        float av = (n < N || SA) ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] : 0.0f;
-        if ((p.delta_softplus & MS_SCAN_A_IS_LOG) && (n < N || SA)) av = -__expf(av);
-        A2[i] = av * kLog2e;
-        h[i] = 0.0f;
+        const bool real = i < NPL && (n < N || SA);
+        float av = real ? p.A[d * p.A_d_stride + (SA ? 0 : n) * p.A_dstate_stride] : 0.0f;
+        if ((p.delta_softplus & MS_SCAN_A_IS_LOG) && real) av = -__expf(av);
+        A2[i / 2][i % 2] = av * kLog2e;
+        h[i / 2][i % 2] = 0.0f;
     }
-    const float Dv = (p.D != nullptr && sg == 0) ? p.D[d] : 0.0f;   // the D*u term is added once, by group 0
-    if (lane < kCW) sbias[lane] = p.delta_bias ? p.delta_bias[d0 + min(lane, max(nvalid, 1) - 1)] : 0.0f;
+    if (lane < kCW) {
+        const int dd_ = d0 + min(lane, max(nvalid, 1) - 1);
+        sbias[lane] = p.delta_bias ? p.delta_bias[dd_] : 0.0f;
+        sDv[lane] = p.D ? p.D[dd_] : 0.0f;
+    }
+    if (NPLp != NPL) {          // pad columns of the row tiles: never written by the staging, read as B = C = 0
+        for (int i = threadIdx.x; i < kCL * RP; i += 64 * kWF) { sB[i] = 0.0f; sC[i] = 0.0f; }
+    }
 
     const int c0w = cb * kCW;                                   // first channel of this wave inside its group
     const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0w * p.u_d_stride;
@@ -100,6 +111,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const bool softplus = (p.delta_softplus & MS_SCAN_SOFTPLUS) != 0;
+    const bool accumulate = (p.delta_softplus & MS_SCAN_ACCUMULATE) != 0;
 
     constexpr bool kGen = MODE == kModeBDL, kRowN = MODE == kModeSS2D;      // see scan_bwd.hip: 32-bit stride copies
     const int u_sd = kGen ? (int)p.u_d_stride : 1, u_sl = (int)p.u_l_stride;
@@ -111,6 +123,7 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const Rows rows(threadIdx.x);
     const unsigned sp_mask = softplus ? 0xFFFFFFFFu : 0u;
     float ru[Tile::NE], rd[Tile::NE], rB[Rows::NE], rC[Rows::NE];
+    float uk[Tile::NE];                      // the u values this lane staged: out = y + D * u is formed by its store
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         if (MODE == kModeSS2D) {
@@ -133,59 +146,73 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
         }
     };
     fetch(0);
-    wave_sync();                                           // sbias visible
+    wave_sync();                                           // sbias / sDv visible
 
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         __syncthreads();                                    // everyone is done with the previous chunk's shared B/C tiles
-        tile.put(su, ru, nvalid, len);
-        tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
-        rows.put(sB, rB, N, len);
-        rows.put(sC, rC, N, len);
+        // stage {delta', delta' * u}: bias + softplus once per element (a bit-select instead of a branch); elements
+        // past the tile edge become the scan identity (a, b) = (1, 0) -- selective_scan_fwd_kernel.cuh:218-222
+#pragma unroll
+        for (int k = 0; k < Tile::NE; ++k) {
+            const bool ok = tile.ok(k, nvalid, len);
+            const float raw = rd[k] + sbias[tile.ck(k)];
+            const float sp = bits_f((f_bits(softplus_ref(raw)) & sp_mask) | (f_bits(raw) & ~sp_mask));
+            const float dl = ok ? sp : 0.0f;
+            uk[k] = ok ? ru[k] : 0.0f;
+            sdd[tile.soff(k)] = (v2f){dl, dl * uk[k]};
+        }
+        rows.template put_t<NPL, RP>(sB, rB, N, len);
+        rows.template put_t<NPL, RP>(sC, rC, N, len);
         __syncthreads();                                    // the B/C tiles are staged by all waves of the workgroup
         if (ch + 1 < n_chunks) fetch(ch + 1);              // lands while this chunk is computed
 
 #pragma unroll 2
         for (int lb = 0; lb < kCL; lb += 4) {
-            float dl_[4], du_[4], y[4], aj[4];
+            float y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                dl_[j] = sdl[(lb + j) * kPitch + c];
-                const float uu = su[(lb + j) * kPitch + c];
-                du_[j] = dl_[j] * uu;
-                y[j] = Dv * uu;
-                aj[j] = SA ? exp2_fast(dl_[j] * A2[0]) : 0.0f;
-            }
+                const v2f dd = sdd[(lb + j) * kPitch + c];
+                const float *bp = sB + (lb + j) * RP + sg * NPLp, *cp = sC + (lb + j) * RP + sg * NPLp;
+                v2f as_ = splat(0.0f);
+                if constexpr (SA) as_ = splat(exp2_fast(dd.x * A2[0].x));
+                v2f y2 = splat(0.0f);
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                float Bv[4], Cv[4];
-                row4(sB + (sg * NPL + i) * kRowPitch, lb, Bv);
-                row4(sC + (sg * NPL + i) * kRowPitch, lb, Cv);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = SA ? aj[j] : exp2_fast(dl_[j] * A2[i]);
-                    h[i] = fmaf(a, h[i], du_[j] * Bv[j]);
-                    y[j] = fmaf(Cv[j], h[i], y[j]);
+                for (int q = 0; q < NP2; ++q) {
+                    const v2f Bv = *reinterpret_cast<const v2f *>(bp + 2 * q), Cv = *reinterpret_cast<const v2f *>(cp + 2 * q);
+                    const v2f a = SA ? as_ : exp2_pk(splat(dd.x) * A2[q]);
+                    h[q] = pk_fma(a, h[q], splat(dd.y) * Bv);
+                    y2 = q == 0 ? Cv * h[q] : pk_fma(Cv, h[q], y2);
                 }
+                y[j] = y2.x + y2.y;
             }
             // sum over the state groups; the owner lanes of slot j end up with the result of position lb + j
             const float yt = sum_groups_scatter4<CW>(y, lane);
-            if (is_group_owner<CW>(lane)) su[(lb + group_slot<CW>(lane)) * kPitch + c] = yt;   // in place: u is in registers
+            if (is_group_owner<CW>(lane)) so[(lb + group_slot<CW>(lane)) * kPitch + c] = yt;
         }
         if (p.x != nullptr && active) {
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 const int n = sg * NPL + i;
+                const float hv = h[i / 2][i % 2];
                 if (BCM == 2) {         // slice-major checkpoints: slice j is what a one-direction backward launch reads
                     const int j = n / nd;
-                    if (n < N) p.x[((((int64_t)j * p.batch + b) * n_chunks + ch) * nd + (n - j * nd)) * p.dim + d] = h[i];
-                } else if (n < N) p.x[(((int64_t)b * n_chunks + ch) * N + n) * p.dim + d] = h[i];
+                    if (n < N) p.x[((((int64_t)j * p.batch + b) * n_chunks + ch) * nd + (n - j * nd)) * p.dim + d] = hv;
+                } else if (n < N) p.x[(((int64_t)b * n_chunks + ch) * N + n) * p.dim + d] = hv;
             }
         }
         wave_sync();
         if (MODE == kModeSS2D) { pm.tab = spos[ch & 1]; pm.tab_base = l0; }      // the prefetch moved pm to the next chunk
-        if (p.delta_softplus & MS_SCAN_ACCUMULATE) tile.template store<true>(su, ob, o_sd, o_sl, l0, pm, nvalid, len);
-        else tile.store(su, ob, o_sd, o_sl, l0, pm, nvalid, len);
+        {   // out = y + D * u (added to what is there under MS_SCAN_ACCUMULATE: each element is read and written by this thread only)
+            char *obb = reinterpret_cast<char *>(ob);
+#pragma unroll
+            for (int k = 0; k < Tile::NE; ++k)
+                if (tile.ok(k, nvalid, len)) {
+                    float *o = reinterpret_cast<float *>(obb + tile.goff(k, o_sd, o_sl, l0, pm));
+                    const float v = fmaf(sDv[tile.ck(k)], uk[k], so[tile.soff(k)]);
+                    *o = accumulate ? *o + v : v;
+                }
+        }
         wave_sync();
     }
 }
@@ -253,7 +280,9 @@ bool act_strides_ok(int64_t sd, int64_t sl, int seqlen) {
 }
 
 int validate_scan(const MsScanParams &p) {
-    if (!p.u || !p.delta || !p.A || !p.B || !p.C) return MS_ERR_NULL;
+    const bool dtf = (p.delta_softplus & MS_SCAN_DT_FUSED) != 0;
+    if (!p.u || (!p.delta && !dtf) || !p.A || !p.B || !p.C) return MS_ERR_NULL;
+    if (dtf && (!p.dt_x || !p.dt_w || p.map_h <= 0 || p.dt_rank < 1)) return MS_ERR_NULL;
     if (p.batch < 0 || p.dim <= 0 || p.seqlen < 0 || p.dstate <= 0 || p.n_groups <= 0) return MS_ERR_SHAPE;
     if (p.dim % p.n_groups != 0) return MS_ERR_SHAPE;
     if (p.dstate > 256) return MS_ERR_DSTATE;
@@ -261,13 +290,16 @@ int validate_scan(const MsScanParams &p) {
     if (p.map_h > 0) {
         if ((int64_t)p.map_h * p.map_w != p.seqlen || p.n_groups % 4 != 0 || p.seqlen >= (1 << 22)) return MS_ERR_SHAPE;
         // SS2D mode needs channel-last activations and projection rows that are contiguous along the state axis
-        if (p.u_d_stride != 1 || p.delta_d_stride != 1 || p.B_dstate_stride != 1 || p.C_dstate_stride != 1) return MS_ERR_STRIDE;
+        if (p.u_d_stride != 1 || (!dtf && p.delta_d_stride != 1) || p.B_dstate_stride != 1 || p.C_dstate_stride != 1) return MS_ERR_STRIDE;
     }
-    if (!act_strides_ok(p.u_d_stride, p.u_l_stride, p.seqlen) || !act_strides_ok(p.delta_d_stride, p.delta_l_stride, p.seqlen) ||
+    if (!act_strides_ok(p.u_d_stride, p.u_l_stride, p.seqlen) || (!dtf && !act_strides_ok(p.delta_d_stride, p.delta_l_stride, p.seqlen)) ||
         !act_strides_ok(p.B_dstate_stride * 4, p.B_l_stride, p.seqlen) || !act_strides_ok(p.C_dstate_stride * 4, p.C_l_stride, p.seqlen))
         return MS_ERR_STRIDE;
     return MS_OK;
 }
+
+bool ss2d_fast_ok(const MsScanParams &p);
+int ss2d_fwd_launch(const MsScanParams &p, int n_chunks, hipStream_t stream);
 
 int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
     int rc = validate_scan(p);
@@ -277,6 +309,8 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
     if (p.map_h > 0 && p.out_d_stride != 1) return MS_ERR_STRIDE;
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
+    if (ss2d_fast_ok(p)) return ss2d_fwd_launch(p, n_chunks, stream);
+    if (p.delta_softplus & MS_SCAN_DT_FUSED) return MS_ERR_UNSUPPORTED;     // the fused projection exists on the fast path only
     if (use_cw8(p, false)) {
         switch (pick_npl(p.dstate, 8)) {
             case 1: return launch_fwd<1, 8>(p, n_chunks, stream);

@@ -61,6 +61,12 @@ def ss2d_forward_oracle(self, x, **kwargs):
     return out
 
 
+def install_one(ss2d):
+    """Rebind the forward of ONE SS2D instance (tests)."""
+    ss2d.forward = types.MethodType(ss2d_forward_oracle, ss2d)
+    return ss2d
+
+
 def install(model):
     """Rebind SS2D.forward on every SS2D instance inside `model` (tests / cpu_baseline only)."""
     from medical_image_classification_amd.medmamba import SS2D

@@ -703,3 +703,77 @@ def test_branch_stream_tuner_and_two_stream_training_trajectory(monkeypatch):
     # Adam amplifies the kernels' summation-order noise step by step: compare the first steps only, then just sanity
     assert all(abs(a - b) <= 5e-3 * max(1.0, abs(a)) for a, b in zip(l0[:4], l1[:4])), (l0[:4], l1[:4])
     assert all(np.isfinite(v) for v in l1 + l2) and l2[-1] < l2[0] and l1[-1] < l1[0]
+
+
+# (d_model, H, W, batch): the four MedMamba-T stage geometries (D = 2 d_model = 96..768, R = 3..24,
+# L = 3136 / 784 / 196 / 49 -- 196 and 49 leave ragged 32-position chunks) and MedMamba-B stage 0 (128 x 128, L = 16384)
+SS2D_STAGE_GEOMETRIES = [(48, 56, 56, 2), (96, 28, 28, 2), (192, 14, 14, 2), (384, 7, 7, 2), (64, 128, 128, 1)]
+
+
+@pytest.mark.parametrize("cfg", SS2D_STAGE_GEOMETRIES, ids=[f"d{c[0]}_{c[1]}x{c[2]}" for c in SS2D_STAGE_GEOMETRIES])
+def test_ss2d_stage_geometries_vs_oracle(cfg):
+    """fp32 SS2D (in_proj -> _SS2DInner: conv, x_proj, dt_proj, the scan in its SS2D addressing mode -- what bench.py runs --
+    merge, out_norm, gate -> out_proj) against oracle/ss2d_oracle (the reference's data flow on CPU, MedMamba.py:466-483)
+    at the real stage sizes: y, dx and every parameter gradient.
+    Tolerances: forward 1e-3 of max|y| (north-star: 1e-3 rel fp32); gradients 2e-3 of their max-norm -- the reference's own
+    rows are du 2x and ddelta 5x the forward's (rtol 6e-4, atol 2e-3) on O(1) data (test_selective_scan.py:398-401,490-502);
+    a max-norm bound is the scale-free form of those rows for gradients whose magnitude varies by orders of magnitude
+    between parameters."""
+    from medical_image_classification_amd import medmamba as mm
+    d_model, H, W, batch = cfg
+    torch.manual_seed(d_model + H)
+    blk = mm.SS2D(d_model=d_model, d_state=16)
+    ref = mm.SS2D(d_model=d_model, d_state=16)
+    ref.load_state_dict(blk.state_dict())
+    ss2d_oracle.install_one(ref)
+    blk.to(dev())
+    x = torch.randn(batch, H, W, d_model)
+    g = torch.randn(batch, H, W, d_model)
+    xr = x.clone().requires_grad_(); xd = x.to(dev()).requires_grad_()
+    yr = ref(xr); yd = blk(xd)
+    yr.backward(g); yd.backward(g.to(dev()))
+    ymax = float(yr.detach().abs().max())
+    assert_close(yd, yr.detach().numpy(), 0, 1e-3 * ymax, "y")
+    assert_close(xd.grad, xr.grad.numpy(), 0, 2e-3 * float(xr.grad.abs().max()), "dx")
+    pr = dict(ref.named_parameters())
+    for k, p in blk.named_parameters():
+        r = pr[k].grad.numpy()
+        assert_close(p.grad, r, 0, 2e-3 * float(np.abs(r).max()), k)
+
+
+@pytest.mark.parametrize("cfg", [(96, 56, 56, 3, 2), (192, 28, 28, 6, 2), (384, 14, 14, 12, 1), (768, 7, 7, 24, 2), (40, 5, 9, 2, 1),
+                                 (36, 3, 3, 32, 1)])
+def test_scan_fused_dt_projection_forward(cfg):
+    """MS_SCAN_DT_FUSED (the Delta projection formed inside the SS2D fast-path kernel, MedMamba.py:400) == the same launch
+    fed with a materialised delta = dts @ Wdt^T: outputs and saved states, at the four stage shapes + ragged ones."""
+    import ctypes
+    from medical_image_classification_amd import _lib
+    from medical_image_classification_amd._lib import MsScanParams
+    from medical_image_classification_amd.ss2d_fused import _ss2d_params
+    D, H, W, R, bs = cfg
+    d = dev(); L, N, C = H * W, 16, R + 32
+    gen = torch.Generator(device=d).manual_seed(R)
+    A = torch.log(1 + 15 * torch.rand(4 * D, N, device=d, generator=gen))
+    Dp = torch.randn(4 * D, device=d, generator=gen)
+    bias = torch.rand(4 * D, device=d, generator=gen) - 3.0
+    xc = torch.randn(bs, H, W, D, device=d, generator=gen)
+    proj = torch.randn(bs, L, 4, C, device=d, generator=gen)
+    wdt = torch.randn(4, D, R, device=d, generator=gen) * R ** -0.5
+    delta = torch.einsum("blkr,kdr->kbld", proj[..., :R].double(), wdt.double()).float().contiguous()
+    lib = _lib.lib()
+    outs = []
+    for fused in (False, True):
+        y4 = torch.full((4, bs, L, D), float("nan"), device=d)
+        xs = torch.full((bs, lib.ms_scan_n_chunks(L), N, 4 * D), float("nan"), device=d)
+        P = MsScanParams()
+        _ss2d_params(P, xc, proj, delta, A, Dp, bias, y4, xs, H, W, N, R, a_is_log=True)
+        if fused:
+            P.delta = None; P.delta_softplus |= 128            # MS_SCAN_DT_FUSED
+            P.dt_x, P.dt_w, P.dt_rank = proj.data_ptr(), wdt.data_ptr(), R
+        _lib.check(lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(d)), "scan")
+        torch.cuda.synchronize()
+        outs.append((y4.cpu().numpy(), xs.cpu().numpy()))
+    assert np.isfinite(outs[1][0]).all() and np.isfinite(outs[1][1]).all()
+    sc = float(np.abs(outs[0][0]).max())
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=0, atol=2e-5 * sc)       # fp32 sum order of the R products only
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=0, atol=2e-5 * float(np.abs(outs[0][1]).max()))
