@@ -274,6 +274,20 @@ int ms_rms_gate_bwd(const float *y, int64_t dir_stride, int ndir, const void *z,
 int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
                        int groups, int dstate, int heads_per_group, int headdim, int reverse, void *stream);
 
+/* ---- the dense projections of SS2D on the matrix cores (in_proj, x_proj, out_proj: MedMamba.py:284,326,397,469,480) --------
+ * C[i][j] (+)= sum_k Aop[i][k] * Bop[j][k]   for i < M, j < N, k < K; bf16 MFMA, fp32 accumulation
+ *   Aop[i][k] = a_trans ? A[k*lda + i] : A[i*lda + k]      A, B: bf16 or fp32 in memory (`*_is_f32`; fp32 operands are rounded to
+ *   Bop[j][k] = b_trans ? B[k*ldb + j] : B[j*ldb + k]      bf16 while a tile is staged -- no separate cast pass, no bf16 weight copy)
+ *   c_mode 0: C fp32 written; 1: C bf16 written; 2: C fp32 ACCUMULATED with atomics (zero it first); 3: like 2 into the
+ *   TRANSPOSED output, C[j*ldc + i] += ... (so the taller of the two weight-gradient orientations can be the row side);
+ *   2 or 3 are required when k_splits > 1 (the k range is cut into k_splits slices evaluated by different workgroups: the weight gradient
+ *   dW = dy^T x reduces over all B*H*W tokens into an output of a few tiles).
+ *   forward  y = x W^T : A = x, B = W;   dx = dy W : A = dy, B = W with b_trans;   dW = dy^T x : A = dy, B = x, both *_trans.
+ * Built combinations: (a_trans, b_trans) in {(0,0), (0,1)} with fp32 B (the weight); (1,1) with any dtypes.
+ * lda / ldb in elements, multiples of 8 (bf16) / 4 (fp32); A, B 16-byte aligned; ldc in elements. */
+int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
+                 void *C, int c_mode, int64_t ldc, int M, int N, int K, int k_splits, void *stream);
+
 /* Diagnostic: one workgroup busy for `cycles` (< 2^32) shader clocks on `stream` -- used to test whether two streams
  * execute concurrently (medmamba.set_branch_streams). */
 int ms_spin(long long cycles, void *stream);

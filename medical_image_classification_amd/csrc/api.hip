@@ -50,9 +50,17 @@ int bn_scratch_floats(int C);
 int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int dy_bf16, const float *gamma, const float *beta,
                     const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
                     float *scratch, int64_t npix, int C, hipStream_t s);
+int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
+                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, hipStream_t stream);
 }  // namespace ms
 
 extern "C" {
+
+int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
+                 void *C, int c_mode, int64_t ldc, int M, int N, int K, int k_splits, void *stream) {
+    return ms::gemm_bf16_dispatch(A, a_is_f32, a_trans, lda, B, b_is_f32, b_trans, ldb, C, c_mode, ldc, M, N, K, k_splits,
+                                  (hipStream_t)stream);
+}
 
 int ms_selective_scan_fwd(const MsScanParams *p, void *stream) {
     if (!p) return MS_ERR_NULL;

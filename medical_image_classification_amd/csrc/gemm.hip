@@ -1,0 +1,272 @@
+// Projection GEMMs of SS2D on the gfx950 matrix cores: in_proj, x_proj, out_proj of MedMamba.py:284,326,397,469,480 and
+// their input / weight gradients -- token matrices with a huge row count (B*H*W = 3 136 .. 200 704) and small feature
+// dimensions (48 .. 1536): every one of them is bound by streaming the activation once, not by the matrix cores.
+//
+//   C[i][j] (+)= sum_k Aop[i][k] * Bop[j][k]          bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulation
+//     Aop[i][k] = a_trans ? A[k*lda + i] : A[i*lda + k]        A, B: bf16 or fp32 in memory (fp32 is rounded to bf16 while
+//     Bop[j][k] = b_trans ? B[k*ldb + j] : B[j*ldb + k]        the tile is staged: no cast kernels, no bf16 weight copies)
+//   forward      y  = x  @ W^T : A = x  (M x K),          B = W (N x K)
+//   input grad   dx = dy @ W   : A = dy (M x N),          B = W (N x K) read transposed (b_trans)
+//   weight grad  dW = dy^T @ x : A = dy read transposed,  B = x read transposed; the reduction over the tokens is split over
+//                                blockIdx.z and the partial tiles are added with fp32 atomics (split-K inside the kernel:
+//                                no partial-sum tensor, no reduction launch)
+// Tile: 128 x BN outputs per 256-thread workgroup, 64-deep k-steps staged through LDS in the canonical [row][k] form
+// (row pitch 72 bf16 = 144 B: the eight 16-byte k-pieces of 16 consecutive rows fall into different bank groups), next
+// k-step's global loads in flight while the current one is multiplied.  The MFMA's A operand is the Bop tile and its B
+// operand the Aop tile, so a lane ends up with FOUR CONSECUTIVE output columns of one output row (16-byte / 8-byte stores).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "medscan.h"
+
+namespace ms {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBM = 128, kBK = 64, kPitch = kBK + 8;       // bf16 elements
+
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-nearest-even; NaN stays NaN (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+// One 8-element piece of a tile row -> 8 bf16.  `p` points at element 0 of the piece; `nvalid` (0..8) of them exist.
+template <bool F32>
+__device__ __forceinline__ bf16x8 load_piece(const void *base, int64_t off, int nvalid) {
+    bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (nvalid >= 8) {
+        if (F32) {
+            const float4 a = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
+            const float4 b = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off + 4);
+            r[0] = f2bf(a.x); r[1] = f2bf(a.y); r[2] = f2bf(a.z); r[3] = f2bf(a.w);
+            r[4] = f2bf(b.x); r[5] = f2bf(b.y); r[6] = f2bf(b.z); r[7] = f2bf(b.w);
+        } else {
+            r = *reinterpret_cast<const bf16x8 *>(static_cast<const unsigned short *>(base) + off);
+        }
+    } else if (nvalid > 0) {
+        // ragged row end: the leading half as one vector when it is whole (x_proj's 4 (R + 2N) = 140.. columns end on a
+        // 16-byte boundary), single elements for the rest
+        int i0 = 0;
+        if (F32 && nvalid >= 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
+            r[0] = f2bf(a.x); r[1] = f2bf(a.y); r[2] = f2bf(a.z); r[3] = f2bf(a.w);
+            i0 = 4;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i >= i0 && i < nvalid)
+                r[i] = F32 ? (short)f2bf(static_cast<const float *>(base)[off + i]) : (short)static_cast<const unsigned short *>(base)[off + i];
+    }
+    return r;
+}
+
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// Stage one [ROWS x 64] tile of op(X) into LDS.  Two phases so that the global loads of the next k-step can be in flight
+// during the MFMAs: fetch() -> registers, put() -> LDS.  Both kinds are staged with 16-byte pieces in the order they have in
+// memory (coalesced loads, one ds_write_b128 per piece):
+//   plain      : X[row*ld + k] -> s[row][k]  (pitch kPitch);  MFMA fragment = one ds_read_b128 (8 consecutive k of a row)
+//   transposed : X[k*ld + row] -> s[k][row]  (pitch ROWS + 16); MFMA fragment = two ds_read_b64_tr_b16 (the hardware's
+//                transposing LDS read: a 16-lane group fetches 4 k-rows x 16 columns and every lane receives the 4 k-values
+//                of ITS column) -- no scattered 2-byte LDS writes, no transposed copy of the weight in memory
+template <int ROWS, bool F32, bool TR>
+struct TileStage {
+    static constexpr int NP = ROWS * kBK / 8 / 256;      // pieces per thread
+    static constexpr int kPT = ROWS + 16;                // pitch of the transposed image (bf16)
+    static constexpr int kLds = TR ? kBK * kPT : ROWS * kPitch;
+    bf16x8 r[NP];
+    __device__ __forceinline__ void fetch(const void *X, int64_t ld, int row0, int k0, int nrows, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int id = tid + 256 * i;
+            if (!TR) {
+                const int row = id / (kBK / 8), kc = id % (kBK / 8);
+                const int gr = row0 + row, gk = k0 + kc * 8;
+                r[i] = load_piece<F32>(X, (int64_t)gr * ld + gk, gr < nrows ? min(8, max(0, K - gk)) : 0);
+            } else {
+                const int k = id / (ROWS / 8), rc = id % (ROWS / 8);
+                const int gk = k0 + k, gr = row0 + rc * 8;
+                r[i] = load_piece<F32>(X, (int64_t)gk * ld + gr, gk < K ? min(8, max(0, nrows - gr)) : 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void put(unsigned short *s, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int id = tid + 256 * i;
+            if (!TR) {
+                const int row = id / (kBK / 8), kc = id % (kBK / 8);
+                *reinterpret_cast<bf16x8 *>(s + row * kPitch + kc * 8) = r[i];
+            } else {
+                const int k = id / (ROWS / 8), rc = id % (ROWS / 8);
+                *reinterpret_cast<bf16x8 *>(s + k * kPT + rc * 8) = r[i];
+            }
+        }
+    }
+    // the MFMA operand fragment of the tile's rows [16 t, 16 t + 16), k-step ks: lane (fr = lane & 15, fq = lane >> 4) gets
+    // op(X)[16 t + fr][32 ks + 8 fq + j], j = 0..7
+    static __device__ __forceinline__ bf16x8 frag(const unsigned short *s, int t, int ks, int lane) {
+        const int fr = lane & 15, fq = lane >> 4;
+        if (!TR) return *reinterpret_cast<const bf16x8 *>(s + (t * 16 + fr) * kPitch + ks * 32 + fq * 8);
+        // lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of the 4 x 16 block; it receives column (lane & 15)
+        const unsigned short *b = s + (ks * 32 + fq * 8 + (fr >> 2)) * kPT + t * 16 + 4 * (fr & 3);
+        typedef bf16x4 __attribute__((address_space(3))) *lds_p;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + 4 * kPT));
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+};
+
+// CMODE: 0 = fp32 store, 1 = bf16 store, 2 = fp32 atomic add (split-K partial), 3 = fp32 atomic add into C^T
+// BM x BN outputs per workgroup; the 4 waves split the ROWS (MT = BM / 64 tiles of 16 rows each), every wave spans all BN
+// columns (TNT = BN / 16 tiles): an activation row block is read once for up to 192 output columns.
+template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR, int CMODE>
+__global__ void __launch_bounds__(256)
+gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int k_per_split) {
+    constexpr int TNT = BN / 16, MT = BM / 64;
+    __shared__ __attribute__((aligned(16))) unsigned short sA[TileStage<BM, AF32, ATR>::kLds];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[TileStage<BN, BF32, BTR>::kLds];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    if (kbeg >= kend) return;
+
+    f32x4 acc[TNT][MT];
+#pragma unroll
+    for (int a = 0; a < TNT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    TileStage<BM, AF32, ATR> ta;
+    TileStage<BN, BF32, BTR> tb;
+    ta.fetch(A, lda, m0, kbeg, M, kend, tid);
+    tb.fetch(B, ldb, n0, kbeg, N, kend, tid);
+    const int fr = lane & 15, fq = lane >> 4;
+    using TA = TileStage<BM, AF32, ATR>;
+    using TB = TileStage<BN, BF32, BTR>;
+    for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+        __syncthreads();                                 // the previous k-step's fragments have been read
+        ta.put(sA, tid);
+        tb.put(sB, tid);
+        __syncthreads();
+        if (k0 + kBK < kend) {                          // next k-step: in flight during the MFMAs below
+            ta.fetch(A, lda, m0, k0 + kBK, M, kend, tid);
+            tb.fetch(B, ldb, n0, k0 + kBK, N, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < kBK / 32; ++ks) {
+            bf16x8 fa[MT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) fa[b] = TA::frag(sA, w * MT + b, ks, lane);
+#pragma unroll
+            for (int a = 0; a < TNT; ++a) {
+                const bf16x8 fb = TB::frag(sB, a, ks, lane);
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    // D[i][j]: i = n within the tile (row 4*fq + r of the accumulator), j = m within the tile (column fr)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int m = m0 + w * (16 * MT) + b * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int a = 0; a < TNT; ++a) {
+            const int n = n0 + a * 16 + fq * 4;
+            if (n >= N) continue;
+            const f32x4 v = acc[a][b];
+            if (CMODE == 2) {
+                float *c = static_cast<float *>(C) + (int64_t)m * ldc + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) atomicAdd(c + r, v[r]);
+            } else if (CMODE == 3) {             // accumulate into the TRANSPOSED output: C[j][i] += (16 lanes = 16 consecutive i)
+                float *c = static_cast<float *>(C) + (int64_t)n * ldc + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) atomicAdd(c + (int64_t)r * ldc, v[r]);
+            } else if (CMODE == 0) {
+                float *c = static_cast<float *>(C) + (int64_t)m * ldc + n;
+                if (n + 4 <= N && (ldc & 3) == 0) *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) c[r] = v[r];
+                }
+            } else {
+                unsigned short *c = static_cast<unsigned short *>(C) + (int64_t)m * ldc + n;
+                if (n + 4 <= N && (ldc & 3) == 0) {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(c) = pk;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) c[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR>
+static void launch_c(int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B, void *C, int M, int N, int K, int64_t lda,
+                     int64_t ldb, int64_t ldc, int kps) {
+    switch (c_mode) {
+        case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 0>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
+        default: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
+    }
+}
+
+template <int BM, int BN>
+static void launch_layout(bool af32, bool bf32, bool atr, bool btr, int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B,
+                          void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int kps) {
+#define MS_GEMM_CASE(AF, BF, AT, BT) \
+    if (af32 == AF && bf32 == BF && atr == AT && btr == BT) { launch_c<BM, BN, AF, BF, AT, BT>(c_mode, grid, s, A, B, C, M, N, K, lda, ldb, ldc, kps); return; }
+    // the combinations the projections use (activations bf16 or fp32, weights fp32)
+    MS_GEMM_CASE(false, true, false, false)   // y = x(bf16) W^T
+    MS_GEMM_CASE(true, true, false, false)    // y = x(fp32) W^T
+    MS_GEMM_CASE(false, true, false, true)    // dx = dy(bf16) W
+    MS_GEMM_CASE(true, true, false, true)     // dx = dy(fp32) W
+    MS_GEMM_CASE(false, false, true, true)    // dW = dy(bf16)^T x(bf16)
+    MS_GEMM_CASE(true, false, true, true)     // dW = dy(fp32)^T x(bf16)
+    MS_GEMM_CASE(false, true, true, true)     // dW = dy(bf16)^T x(fp32)
+    MS_GEMM_CASE(true, true, true, true)      // dW = dy(fp32)^T x(fp32)
+#undef MS_GEMM_CASE
+}
+
+static bool combo_built(bool af32, bool bf32, bool atr, bool btr) {
+    if (!atr && !btr) return bf32;
+    if (!atr && btr) return bf32;
+    return atr && btr;
+}
+
+int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
+                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, hipStream_t stream) {
+    if (!A || !B || !C) return MS_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || k_splits < 1 || c_mode < 0 || c_mode > 3) return MS_ERR_SHAPE;
+    if (k_splits > 1 && c_mode < 2) return MS_ERR_SHAPE;
+    if (!combo_built(a_f32, b_f32, a_trans, b_trans)) return MS_ERR_UNSUPPORTED;
+    // 16-byte pieces: leading dimensions in units of 8 bf16 / 4 fp32, 16-byte aligned bases
+    const int64_t ga = a_f32 ? 4 : 8, gb = b_f32 ? 4 : 8;
+    if (lda % ga || ldb % gb || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return MS_ERR_STRIDE;
+    int kps = (K + k_splits - 1) / k_splits;
+    kps = (kps + kBK - 1) / kBK * kBK;
+    const int nz = (K + kps - 1) / kps;
+    // column block: the narrowest of 64 / 128 / 192 that covers N in the fewest passes over the rows
+    const int passes = (N + 191) / 192;
+    const int per = (N + passes - 1) / passes;
+    const int bn = per <= 64 ? 64 : per <= 128 ? 128 : 192;
+    const int ny = (N + bn - 1) / bn;
+    // row block 64 instead of 128 when 128-row blocks would not fill the chip
+    const bool small = (int64_t)((M + 127) / 128) * ny * nz < 512;
+    const int bm = small ? 64 : 128;
+    const dim3 grid((M + bm - 1) / bm, ny, nz);
+#define MS_GEMM_TILE(BM_, BN_) \
+    if (bm == BM_ && bn == BN_) launch_layout<BM_, BN_>(a_f32, b_f32, a_trans, b_trans, c_mode, grid, stream, A, B, C, M, N, K, lda, ldb, ldc, kps);
+    MS_GEMM_TILE(128, 64) MS_GEMM_TILE(128, 128) MS_GEMM_TILE(128, 192) MS_GEMM_TILE(64, 64) MS_GEMM_TILE(64, 128) MS_GEMM_TILE(64, 192)
+#undef MS_GEMM_TILE
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+}  // namespace ms

@@ -1,0 +1,125 @@
+"""The dense projections of SS2D (in_proj / x_proj / out_proj, MedMamba.py:284,326,397,469,480) on the hand-written
+MFMA kernel `ms_gemm_bf16` (csrc/gemm.hip; C ABI in include/medscan.h): bf16 matrix cores, fp32 accumulation.
+
+  forward      y  = x @ W^T        activations bf16 or fp32 in memory (fp32 is rounded to bf16 while a tile is staged),
+  input grad   dx = dy @ W         the weight is read as the fp32 master copy -- no bf16 weight copies, no cast kernels
+  weight grad  dW = dy^T @ x       reduction over the B*H*W tokens split over workgroups inside the kernel (fp32 atomics)
+
+This is the autocast-bf16 path (what the reference's nn.Linear / einsum do under `torch.autocast(bfloat16)`); fp32 runs keep
+the stock fp32 GEMMs.  CUDA (HIP) tensors only -- no CPU fallback.
+"""
+import torch
+
+from . import _lib
+
+
+def _is_f32(t):
+    if t.dtype == torch.float32:
+        return 1
+    if t.dtype == torch.bfloat16:
+        return 0
+    raise RuntimeError(f"ms_gemm_bf16: bf16 or fp32 operands only, got {t.dtype}")
+
+
+def _k_splits(k_len, out_blocks, out_elems):
+    """Slices of the reduction for the weight gradient: about one workgroup per CU in total, every slice at least 256 deep,
+    and at most ~6 MB of fp32 atomics over all slices (measured on MI355X, tools/sweep_gemm_dw.py: more slices lose to
+    same-address atomic contention and atomic volume, fewer to exposed load latency)."""
+    want = max(1, 256 // max(1, out_blocks))
+    return max(1, min(want, k_len // 256, max(1, 1_500_000 // max(1, out_elems))))
+
+
+def _blocks(rows, cols):
+    """Workgroup tiles ms_gemm_bf16 uses for a (rows x cols) output (128-row blocks, 64/128/192-column blocks)."""
+    passes = (cols + 191) // 192
+    per = -(-cols // passes)
+    bn = 64 if per <= 64 else 128 if per <= 128 else 192
+    return -(-rows // 128) * -(-cols // bn)
+
+
+def weight_grad(dy, x, out=None):
+    """dW (N, K) (+)= dy^T @ x for dy (M, N), x (M, K): split-K inside the kernel, the taller of (N, K) on the row side."""
+    N, K = dy.shape[1], x.shape[1]
+    M = dy.shape[0]
+    if out is None:
+        out = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+    if N >= K:
+        return gemm(dy, x, a_trans=True, b_trans=True, out=out, accumulate=True, k_splits=_k_splits(M, _blocks(N, K), N * K))
+    # (K x N) orientation, accumulated into the transposed output
+    _lib.require_cuda(dy, x)
+    ks = _k_splits(M, _blocks(K, N), N * K)
+    with _lib.on_device(dy.device):
+        _lib.check(_lib.lib().ms_gemm_bf16(x.data_ptr(), _is_f32(x), 1, x.stride(0), dy.data_ptr(), _is_f32(dy), 1, dy.stride(0),
+                                           out.data_ptr(), 3, out.stride(0), K, N, M, ks, _lib.current_stream_ptr(dy.device)),
+                   "ms_gemm_bf16")
+    return out
+
+
+def gemm(a, b, a_trans=False, b_trans=False, out=None, out_dtype=torch.float32, accumulate=False, k_splits=1):
+    """C[i, j] (+)= sum_k Aop[i, k] * Bop[j, k];  a, b: 2-D row-major (unit inner stride) bf16 / fp32 CUDA tensors,
+    Aop = a.T if a_trans else a, Bop = b.T if b_trans else b.  Returns C (M, N) in `out_dtype` (fp32 when accumulating)."""
+    _lib.require_cuda(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise RuntimeError("ms_gemm_bf16: 2-D operands with unit inner stride")
+    M, K = (a.shape[1], a.shape[0]) if a_trans else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if b_trans else b.shape
+    if K != Kb:
+        raise RuntimeError(f"ms_gemm_bf16: inner dimensions differ ({K} vs {Kb})")
+    if accumulate or k_splits > 1:
+        c_mode = 2
+        if out is None:
+            out = torch.zeros((M, N), device=a.device, dtype=torch.float32)
+    else:
+        c_mode = 1 if out_dtype == torch.bfloat16 else 0
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16 if c_mode == 1 else torch.float32)
+    if out.stride(1) != 1 or tuple(out.shape) != (M, N):
+        raise RuntimeError("ms_gemm_bf16: bad output tensor")
+    with _lib.on_device(a.device):
+        _lib.check(_lib.lib().ms_gemm_bf16(a.data_ptr(), _is_f32(a), int(a_trans), a.stride(0), b.data_ptr(), _is_f32(b), int(b_trans),
+                                           b.stride(0), out.data_ptr(), c_mode, out.stride(0), M, N, K, int(k_splits),
+                                           _lib.current_stream_ptr(a.device)), "ms_gemm_bf16")
+    return out
+
+
+def _rows(t):
+    """(.., K) -> (M, K) view usable by the kernel (unit inner stride, uniform row stride) or a contiguous copy."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.dtype not in (torch.float32, torch.bfloat16):
+        t2 = t2.float()
+    if t2.dtype == torch.bfloat16 and t2.shape[1] % 8 != 0:
+        t2 = t2.float()                      # rows must be multiples of 16 bytes: such widths go through as fp32
+    esz = 4 if t2.dtype == torch.float32 else 8
+    if t2.stride(1) != 1 or t2.stride(0) % esz != 0 or t2.data_ptr() % 16 != 0:
+        t2 = t2.contiguous()
+    return t2
+
+
+class _LinearMFMA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, out_fp32):
+        xm = _rows(x)
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        y = gemm(xm, w, out_dtype=torch.float32 if out_fp32 else torch.bfloat16)
+        ctx.save_for_backward(xm, w)
+        ctx.xshape, ctx.xdtype, ctx.wdtype = x.shape, x.dtype, weight.dtype
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, w = ctx.saved_tensors
+        N, K = w.shape
+        dym = _rows(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dym, w, b_trans=True, out_dtype=torch.bfloat16 if ctx.xdtype == torch.bfloat16 else torch.float32)
+            dx = dx.view(ctx.xshape)
+        dw = weight_grad(dym, xm)
+        return dx, dw.to(ctx.wdtype), None
+
+
+def linear_mfma(x, weight, out_fp32=False):
+    """F.linear(x, weight) (no bias) on ms_gemm_bf16: bf16 MFMA with fp32 accumulation; bf16 result unless out_fp32."""
+    return _LinearMFMA.apply(x, weight, out_fp32)

@@ -20,7 +20,9 @@ import torch
 
 from . import _lib
 from ._lib import MsScanBwdParams, MsScanParams
+from .gemm_ops import gemm, weight_grad
 from .selective_scan_interface import TIMER, algorithmic_bytes
+from .ss2d_ops import _MFMA_GEMM, _MFMA_MIN_ROWS
 
 
 class _DWConvSiLUNHWC(torch.autograd.Function):
@@ -311,7 +313,8 @@ class _SS2DInner(torch.autograd.Function):
         cw, cb = f32(conv_w), (f32(conv_b) if conv_b is not None else None)
         wdt, A, Dv, bias, gamma, beta = f32(wdt), f32(A_logs), f32(Ds), f32(dt_bias), f32(gamma), f32(beta)
         wx = xproj_w.detach().reshape(4 * C, D)
-        wx = (wx.to(mm_dtype) if mm_dtype is not None else wx.float()).contiguous()
+        mfma = mm_dtype == torch.bfloat16 and _MFMA_GEMM and D % 8 == 0 and M >= _MFMA_MIN_ROWS       # x_proj on ms_gemm_bf16 (fp32 operands read in place)
+        wx = (wx.to(mm_dtype) if (mm_dtype is not None and not mfma) else wx.float()).contiguous()
         dev = xz.device
         xc = torch.empty((B, H, W, D), device=dev, dtype=torch.float32)
         y4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
@@ -321,8 +324,12 @@ class _SS2DInner(torch.autograd.Function):
         with _lib.on_device(dev):
             _lib.check(lib.ms_dwconv3x3_silu_nhwc_fwd(xz.data_ptr(), xz_bf16, cw.data_ptr(), cb.data_ptr() if cb is not None else None,
                                                       xc.data_ptr(), B, D, H, W, D2, stream), "ms_dwconv3x3_silu_nhwc_fwd")
-            xm = xc.view(M, D).to(mm_dtype) if mm_dtype is not None else xc.view(M, D)
-            proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())   # (M, 4C)
+            if mfma:
+                xm = None
+                proj = gemm(xc.view(M, D), wx)                                                               # (M, 4C) fp32
+            else:
+                xm = xc.view(M, D).to(mm_dtype) if mm_dtype is not None else xc.view(M, D)
+                proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())
             delta = _dtproj_fwd(proj, wdt, B, L, D, R, C)
             P = MsScanParams()
             _ss2d_params(P, xc, proj, delta, A, Dv, bias, y4, x_state, H, W, N, R, a_is_log=True)
@@ -332,9 +339,10 @@ class _SS2DInner(torch.autograd.Function):
             _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
                                           beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), M, D, stream),
                        "ms_ln_gate_fwd")
-        ctx.save_for_backward(xz, xc, xm if mm_dtype is not None else None, wx, proj, delta, x_state, y4, cw, cb, wdt, A, Dv, bias,
-                              gamma, beta)
+        ctx.save_for_backward(xz, xc, xm if (mm_dtype is not None and not mfma) else None, wx, proj, delta, x_state, y4, cw, cb, wdt,
+                              A, Dv, bias, gamma, beta)
         ctx.geom = (N, R, float(eps))
+        ctx.mfma = mfma
         ctx.dtypes = (conv_w.dtype, conv_b.dtype if conv_b is not None else None, xproj_w.dtype, xproj_w.shape)
         return out
 
@@ -381,14 +389,19 @@ class _SS2DInner(torch.autograd.Function):
             dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C)
             # x_proj backward: input gradient in fp32 straight out of the GEMM, split-K weight gradient
             dpm = dproj.view(M, 4 * C)
-            if xm is not None:
+            if ctx.mfma:
+                dxe = gemm(dpm, wx, b_trans=True)                      # fp32 dproj read in place, fp32 result
+                dwx = weight_grad(dpm, xc.view(M, D))
+            elif xm is not None:
                 dpm = dpm.to(xm.dtype)
                 dxe = torch.mm(dpm, wx, out_dtype=torch.float32)
             else:
                 xm = xc.view(M, D)
                 dxe = torch.mm(dpm, wx)
             S = _split_k(M)
-            if S > 1:
+            if ctx.mfma:
+                pass
+            elif S > 1:
                 a, b = dpm.view(S, M // S, 4 * C).transpose(1, 2), xm.view(S, M // S, D)
                 dwx = (torch.bmm(a, b, out_dtype=torch.float32) if xm.dtype != torch.float32 else torch.bmm(a, b)).sum(dim=0)
             else:

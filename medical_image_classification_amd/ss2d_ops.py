@@ -164,9 +164,25 @@ class _LinearSplitK(torch.autograd.Function):
         return (dx.view(ctx.xshape).to(ctx.xdtype) if dx is not None else None), dw.to(ctx.wdtype), None
 
 
+import os
+
+# the bf16-autocast projections run on the hand-written MFMA kernel (gemm_ops / csrc/gemm.hip); MEDSCAN_MFMA_GEMM=0 puts them
+# back on the BLAS library (kernel-variant experiments)
+_MFMA_GEMM = os.environ.get("MEDSCAN_MFMA_GEMM", "1") == "1"
+# token-matrix height from which the MFMA kernel is used (below it the library GEMM wins in situ: measured)
+_MFMA_MIN_ROWS = int(os.environ.get("MEDSCAN_MFMA_MIN_ROWS", "32768"))
+
+
 def linear_splitk(x, weight, out_fp32=False):
-    """F.linear(x, weight) (no bias) with a split-K weight gradient; falls back to F.linear for small row counts.
-    out_fp32: return fp32 even when the GEMM runs in bf16 under autocast."""
+    """F.linear(x, weight) (no bias) for the token matrices of SS2D (in_proj / out_proj / PatchMerging reduction,
+    MedMamba.py:284,326,208).  Under bf16 autocast: ms_gemm_bf16 (hand-written MFMA kernel: fp32 master weight read
+    directly, split-K weight gradient inside the kernel).  fp32: library GEMMs with a split-K weight gradient; F.linear for
+    small row counts.  out_fp32: return fp32 even when the GEMM runs in bf16 under autocast."""
+    if (_MFMA_GEMM and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and weight.shape[1] % 8 == 0 and x.numel() // x.shape[-1] >= _MFMA_MIN_ROWS):
+        from .gemm_ops import linear_mfma
+        with torch.autocast(device_type="cuda", enabled=False):
+            return linear_mfma(x, weight, out_fp32)
     if x.is_cuda and x.numel() // x.shape[-1] >= 8192:
         return _LinearSplitK.apply(x, weight, out_fp32)
     y = torch.nn.functional.linear(x, weight)

@@ -1,0 +1,120 @@
+"""GPU parity of the hand-written MFMA projection GEMM (csrc/gemm.hip) against float64 products of the SAME bf16-rounded
+operands (so only the accumulation order differs): every operand layout / dtype the projections use, ragged edges in all
+three dimensions, split-K accumulation, and the autograd wrapper against F.linear."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _round(t):
+    return t.to(torch.bfloat16).double() if t.dtype == torch.float32 else t.double()
+
+
+# (M, N, K): MedMamba-T projection shapes (batch reduced) + ragged ones
+SHAPES = [(3136 * 2, 192, 48), (784 * 2, 152, 192), (196 * 2, 768, 192), (49 * 2, 384, 768), (200, 140, 96), (129, 68, 40),
+          (1, 4, 8), (1000, 48, 96), (256, 224, 768)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{s[0]}x{s[1]}x{s[2]}" for s in SHAPES])
+@pytest.mark.parametrize("a_f32", [False, True])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_forward_and_input_grad_layouts(shape, a_f32, out_bf16):
+    from medical_image_classification_amd.gemm_ops import gemm
+    M, N, K = shape
+    gen = torch.Generator(device=dev()).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev(), generator=gen)
+    if not a_f32:
+        a = a.to(torch.bfloat16)
+    w = torch.randn(N, K, device=dev(), generator=gen) * K ** -0.5
+    od = torch.bfloat16 if out_bf16 else torch.float32
+    y = gemm(a, w, out_dtype=od)                              # y = a W^T
+    ref = _round(a) @ _round(w).t()
+    tol = (8e-3 if out_bf16 else 2e-5) * float(ref.abs().max())
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=tol)
+    dy = torch.randn(M, N, device=dev(), generator=gen)
+    if not a_f32 and N % 8 == 0:                              # bf16 rows must be multiples of 16 bytes (x_proj's 4(R+2N) = 140.. columns are fp32)
+        dy = dy.to(torch.bfloat16)
+    dx = gemm(dy, w, b_trans=True, out_dtype=od)              # dx = dy W
+    ref = _round(dy) @ _round(w)
+    tol = (8e-3 if out_bf16 else 2e-5) * float(ref.abs().max())
+    np.testing.assert_allclose(dx.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{s[0]}x{s[1]}x{s[2]}" for s in SHAPES])
+@pytest.mark.parametrize("dt", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("splits", [1, 4])
+def test_weight_grad_split_k(shape, dt, splits):
+    from medical_image_classification_amd.gemm_ops import gemm
+    M, N, K = shape
+    gen = torch.Generator(device=dev()).manual_seed(M * 3 + N)
+    dy = torch.randn(M, N, device=dev(), generator=gen)
+    x = torch.randn(M, K, device=dev(), generator=gen)
+    if M % 8 != 0:                                            # transposed reads take 8 consecutive rows: pad the token axis
+        pad = 8 - M % 8
+        dy = torch.cat([dy, torch.zeros(pad, N, device=dev())]); x = torch.cat([x, torch.zeros(pad, K, device=dev())])
+    if not dt[0] and N % 8 == 0:
+        dy = dy.to(torch.bfloat16)
+    if not dt[1] and K % 8 == 0:
+        x = x.to(torch.bfloat16)
+    dw = gemm(dy, x, a_trans=True, b_trans=True, k_splits=splits)     # dW = dy^T x
+    ref = _round(dy).t() @ _round(x)
+    np.testing.assert_allclose(dw.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()) + 1e-6)
+    dw2 = gemm(dy, x, a_trans=True, b_trans=True, out=dw, accumulate=True)     # accumulates into what is there
+    np.testing.assert_allclose(dw2.double().cpu().numpy(), 2 * ref.cpu().numpy(), rtol=0, atol=6e-5 * float(ref.abs().max()) + 1e-6)
+
+
+def test_strided_rows_and_errors():
+    from medical_image_classification_amd.gemm_ops import gemm
+    gen = torch.Generator(device=dev()).manual_seed(1)
+    big = torch.randn(300, 256, device=dev(), generator=gen)
+    a = big[:, 64:160]                                        # row stride 256, 16-byte aligned column offset
+    w = torch.randn(72, 96, device=dev(), generator=gen)
+    y = gemm(a, w)
+    ref = _round(a) @ _round(w).t()
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+    with pytest.raises(RuntimeError):
+        gemm(a, torch.randn(72, 95, device=dev()))           # inner dimensions differ
+    with pytest.raises(RuntimeError):
+        gemm(a.cpu(), w.cpu())                                # no CPU fallback
+
+
+@pytest.mark.parametrize("cfg", [(2, 56, 56, 48, 192, True), (2, 14, 14, 192, 176, False), (1, 7, 7, 768, 384, True)])
+def test_linear_mfma_autograd_vs_f_linear(cfg):
+    from medical_image_classification_amd.gemm_ops import linear_mfma
+    B, H, W, K, N, bf = cfg
+    gen = torch.Generator(device=dev()).manual_seed(K)
+    x = torch.randn(B, H, W, K, device=dev(), generator=gen)
+    if bf:
+        x = x.to(torch.bfloat16)
+    x = x.requires_grad_()
+    w = (torch.randn(N, K, device=dev(), generator=gen) * K ** -0.5).requires_grad_()
+    g = torch.randn(B, H, W, N, device=dev(), generator=gen)
+    y = linear_mfma(x, w, out_fp32=True)
+    y.backward(g)
+    x64 = _round(x.detach()).requires_grad_(); w64 = _round(w.detach()).requires_grad_()
+    y64 = torch.nn.functional.linear(x64, w64)
+    y64.backward(g.double())
+    sc = lambda t: float(t.abs().max())
+    np.testing.assert_allclose(y.detach().double().cpu().numpy(), y64.detach().cpu().numpy(), rtol=0, atol=2e-5 * sc(y64.detach()))
+    # the gradients see dy rounded to bf16 (what the reference's autocast GEMMs do as well): 2^-9 relative per term
+    np.testing.assert_allclose(x.grad.double().cpu().numpy(), x64.grad.cpu().numpy(), rtol=0, atol=8e-3 * sc(x64.grad))
+    np.testing.assert_allclose(w.grad.double().cpu().numpy(), w64.grad.cpu().numpy(), rtol=0, atol=8e-3 * sc(w64.grad))
+
+
+@pytest.mark.parametrize("shape", [(3136 * 2, 48, 96), (784, 96, 192), (392, 192, 48), (200, 36, 140)])
+def test_weight_grad_orientation(shape):
+    """weight_grad puts the taller of (N, K) on the row side and accumulates into the transposed output when it swaps."""
+    from medical_image_classification_amd.gemm_ops import weight_grad
+    M, N, K = shape
+    gen = torch.Generator(device=dev()).manual_seed(N)
+    dy = torch.randn(M, N, device=dev(), generator=gen); x = torch.randn(M, K, device=dev(), generator=gen)
+    dw = weight_grad(dy, x)
+    ref = _round(dy).t() @ _round(x)
+    np.testing.assert_allclose(dw.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))
