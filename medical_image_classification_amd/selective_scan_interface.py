@@ -70,10 +70,21 @@ def _act_strides(t, dpg):
     return sb, dpg * sd, sd, sl
 
 
-def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, delta_softplus):
+_SLICE = 16     # states per launch: the backward kernels keep <= 16 states of a channel in registers
+
+
+def _state_slices(N):
+    """The state axis in slices of <= 16 states.  The recurrence is independent per state and y / du / ddelta are sums
+    over the states, so dstate up to the reference's 256 (selective_scan.cpp:262) is covered by ceil(N / 16) launches whose
+    results add up (MS_SCAN_ACCUMULATE from the second slice on) -- what `mamba_chunk_scan_combined` in cnn_mamba.py does
+    for the SSD blocks."""
+    return [(s0, min(N, s0 + _SLICE)) for s0 in range(0, N, _SLICE)]
+
+
+def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, delta_softplus, accumulate=False):
     batch, dim, L = u.shape
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, L, A.shape[1], B.shape[1]
-    P.delta_softplus = int(bool(delta_softplus))
+    P.delta_softplus = int(bool(delta_softplus)) | (4 if accumulate else 0)      # MS_SCAN_SOFTPLUS | MS_SCAN_ACCUMULATE
     P.map_h = P.map_w = 0
     dpg = dim // B.shape[1]
     P.u_batch_stride, P.u_group_stride, P.u_d_stride, P.u_l_stride = _act_strides(u, dpg)
@@ -172,19 +183,29 @@ class SelectiveScanFn(torch.autograd.Function):
         bc = delta_bias.contiguous() if delta_bias is not None else None
         out = torch.empty_like(df)
         n_chunks = lib.ms_scan_n_chunks(L)
-        x = torch.empty((batch, n_chunks, N, dim), device=u.device, dtype=torch.float32)
+        slices = _state_slices(N)
+        # saved states per slice: (n_slices, batch, n_chunks, <=16, dim); one slice = the reference-sized problem
+        x = torch.empty((len(slices), batch, n_chunks, min(N, _SLICE), dim), device=u.device, dtype=torch.float32)
         if batch > 0 and L > 0:
-            P = MsScanParams()
-            _fill_fwd(P, uf, df, Af, Bg, Cg, Dc, bc, out, x, delta_softplus)
-            with _lib.on_device(u.device):
-                rc = TIMER.launch("scan_fwd", algorithmic_bytes(batch, dim, L, N, Bg.shape[1], False), u.device,
-                                  lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(u.device)))
-                _lib.check(rc, "ms_selective_scan_fwd")
+            for i, (s0, s1) in enumerate(slices):
+                P = MsScanParams()
+                xi = x[i] if s1 - s0 == x.shape[3] else x[i].view(-1)[:batch * n_chunks * (s1 - s0) * dim].view(batch, n_chunks, s1 - s0, dim)
+                _fill_fwd(P, uf, df, Af[:, s0:s1], Bg[:, :, s0:s1], Cg[:, :, s0:s1], Dc if i == 0 else None, bc, out, xi,
+                          delta_softplus, accumulate=i > 0)
+                with _lib.on_device(u.device):
+                    rc = TIMER.launch("scan_fwd", algorithmic_bytes(batch, dim, L, s1 - s0, Bg.shape[1], False), u.device,
+                                      lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(u.device)))
+                    _lib.check(rc, "ms_selective_scan_fwd")
         ctx.delta_softplus = bool(delta_softplus)
         ctx.has_z = z is not None
         ctx.in_dtype = in_dtype
         ctx.has_D, ctx.has_bias = D is not None, delta_bias is not None
-        last_state = x[:, -1].transpose(1, 2) if n_chunks > 0 else uf.new_zeros((batch, dim, N))
+        if n_chunks > 0:
+            last_state = torch.cat([(x[i] if s1 - s0 == x.shape[3] else
+                                     x[i].view(-1)[:batch * n_chunks * (s1 - s0) * dim].view(batch, n_chunks, s1 - s0, dim))[:, -1]
+                                    for i, (s0, s1) in enumerate(slices)], dim=1).transpose(1, 2)
+        else:
+            last_state = uf.new_zeros((batch, dim, N))
         if z is None:
             ctx.save_for_backward(uf, df, Af, Bg, Cg, Dc, bc, x)
             res = out.to(in_dtype)
@@ -216,9 +237,12 @@ class SelectiveScanFn(torch.autograd.Function):
         dC = torch.zeros_like(dB)
         dD = torch.zeros_like(Dc) if Dc is not None else None
         dbias = torch.zeros_like(bc) if bc is not None else None
-        if batch > 0 and L > 0:
+        n_chunks = x.shape[2]
+        for i, (s0, s1) in enumerate(_state_slices(N) if (batch > 0 and L > 0) else []):
             Q = MsScanBwdParams()
-            _fill_fwd(Q.f, uf, df, Af, Bg, Cg, Dc, bc, None, x, ctx.delta_softplus)
+            xi = x[i] if s1 - s0 == x.shape[3] else x[i].view(-1)[:batch * n_chunks * (s1 - s0) * dim].view(batch, n_chunks, s1 - s0, dim)
+            _fill_fwd(Q.f, uf, df, Af[:, s0:s1], Bg[:, :, s0:s1], Cg[:, :, s0:s1], Dc if i == 0 else None, bc, None, xi,
+                      ctx.delta_softplus, accumulate=i > 0)
             dpg = dim // G
             Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = _act_strides(g, dpg)
             Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = _act_strides(du, dpg)
@@ -226,19 +250,25 @@ class SelectiveScanFn(torch.autograd.Function):
             Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = dB.stride()
             Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = dC.stride()
             Q.dout, Q.du, Q.ddelta = g.data_ptr(), du.data_ptr(), ddelta.data_ptr()
-            Q.dA, Q.dB, Q.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
-            Q.dD = dD.data_ptr() if dD is not None else None
+            # the kernels write dA as a dense (dim, states of this launch) block: one scratch block per slice
+            dAi = dA if len(_state_slices(N)) == 1 else torch.zeros((dim, s1 - s0), device=Af.device, dtype=torch.float32)
+            Q.dA, Q.dB, Q.dC = dAi.data_ptr(), dB[:, :, s0:s1].data_ptr(), dC[:, :, s0:s1].data_ptr()
+            Q.dD = dD.data_ptr() if (dD is not None and i == 0) else None
             Q.ddelta_bias = dbias.data_ptr() if dbias is not None else None
             with _lib.on_device(uf.device):
-                rc = TIMER.launch("scan_bwd", algorithmic_bytes(batch, dim, L, N, G, True), uf.device,
+                rc = TIMER.launch("scan_bwd", algorithmic_bytes(batch, dim, L, s1 - s0, G, True), uf.device,
                                   lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(uf.device)))
                 _lib.check(rc, "ms_selective_scan_bwd")
+            if dAi is not dA:
+                dA[:, s0:s1] = dAi
 
         def back_to(grad, shape, dtype):   # undo _as_groups
             if len(shape) == 2:
                 grad = grad.sum(dim=(0, 3)) if grad.shape[1] == shape[0] else grad
             elif len(shape) == 3:
-                grad = grad.squeeze(1)
+                # (batch, N, L) operand: one group -- or `dim` groups when the OTHER operand was a per-channel constant
+                # (both were expanded to per-channel groups): sum the expanded axis back
+                grad = grad.squeeze(1) if grad.shape[1] == 1 else grad.sum(dim=1)
             elif grad.shape[1] != shape[1]:
                 grad = grad.view(shape[0], shape[1], -1, shape[2], shape[3]).sum(2)
             return grad.to(dtype)

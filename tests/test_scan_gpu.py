@@ -345,3 +345,57 @@ def test_reference_test_grid(seqlen, itype):
             close(t["D"].grad, gr["dD"], rtolw, atolw * max(1.0, float(np.abs(gr["dD"]).max()) / 50), "dD " + tag)
         if has_bias:
             close(t["bias"].grad, gr["ddelta_bias"], rtolw, atolw * max(1.0, float(np.abs(gr["ddelta_bias"]).max()) / 50), "dbias " + tag)
+
+
+@pytest.mark.parametrize("N", [17, 32, 64, 100, 256])
+def test_wide_state_axis_slices(N):
+    """dstate up to the reference's 256 (selective_scan.cpp:262): ceil(N / 16) launches over state slices whose outputs and
+    du / ddelta add up; output, last state and every gradient vs the C oracle."""
+    batch, dim, L, G = 2, 24, 70, 2
+    t_cpu, g = make_inputs(batch, dim, N, L, G, seed=N)
+    d = dev()
+    t = {k: v.to(d).requires_grad_() for k, v in t_cpu.items()}
+    out, last = run_hip(t, True)
+    npy = {k: v.numpy() for k, v in t_cpu.items()}
+    ref_out, ref_last = so.scan_fwd(npy["u"], npy["delta"], npy["A"], npy["B"], npy["C"], npy["D"], None, npy["delta_bias"], True)
+    sc = lambda a: max(1.0, float(np.abs(a).max()))
+    close(out, ref_out, RTOL, ATOL * sc(ref_out), "out")
+    close(last, ref_last, RTOL, ATOL, "last_state")
+    out.backward(g.to(d))
+    ref = so.scan_bwd(npy["u"], npy["delta"], npy["A"], npy["B"], npy["C"], npy["D"], None, npy["delta_bias"], g.numpy(), True)
+    close(t["u"].grad, ref["du"], 2 * RTOL, 2 * ATOL * sc(ref["du"]), "du")
+    close(t["delta"].grad, ref["ddelta"], 5 * RTOL, 5 * ATOL * sc(ref["ddelta"]), "ddelta")
+    close(t["A"].grad, ref["dA"], 1e-3, 5e-3 * sc(ref["dA"]), "dA")
+    close(t["B"].grad, ref["dB"], RTOL, ATOL * sc(ref["dB"]), "dB")
+    close(t["C"].grad, ref["dC"], RTOL, ATOL * sc(ref["dC"]), "dC")
+    close(t["D"].grad, ref["dD"], 1e-3, 1e-3 * sc(ref["dD"]), "dD")
+    close(t["delta_bias"].grad, ref["ddelta_bias"], 1e-3, 1e-3 * sc(ref["ddelta_bias"]), "ddelta_bias")
+
+
+@pytest.mark.parametrize("const_b", [True, False])
+def test_mixed_variable_and_constant_bc(const_b):
+    """One of B / C input-dependent (batch, N, L), the other a per-channel constant (dim, N) -- the reference's
+    is_variable_B != is_variable_C case (selective_scan.cpp:244-259): gradients come back in the operands' own shapes."""
+    from medical_image_classification_amd import selective_scan_fn
+    batch, dim, N, L = 2, 12, 8, 40
+    gen = torch.Generator().manual_seed(5 + const_b)
+    u = torch.randn(batch, dim, L, generator=gen); delta = 0.5 * torch.rand(batch, dim, L, generator=gen)
+    A = -0.5 * torch.rand(dim, N, generator=gen)
+    var = torch.randn(batch, N, L, generator=gen); con = torch.randn(dim, N, generator=gen)
+    g = torch.randn(batch, dim, L, generator=gen)
+    d = dev()
+    t = [v.to(d).requires_grad_() for v in (u, delta, A, con if const_b else var, var if const_b else con)]
+    out = selective_scan_fn(t[0], t[1], t[2], t[3], t[4], None, None, None, True)
+    out.backward(g.to(d))
+    # oracle on the expanded operands
+    Bx = (con.view(1, dim, N, 1).expand(batch, dim, N, L) if const_b else var.view(batch, 1, N, L).expand(batch, dim, N, L)).contiguous()
+    Cx = (var.view(batch, 1, N, L).expand(batch, dim, N, L) if const_b else con.view(1, dim, N, 1).expand(batch, dim, N, L)).contiguous()
+    ref_out, _ = so.scan_fwd(u.numpy(), delta.numpy(), A.numpy(), Bx.numpy(), Cx.numpy(), None, None, None, True)
+    ref = so.scan_bwd(u.numpy(), delta.numpy(), A.numpy(), Bx.numpy(), Cx.numpy(), None, None, None, g.numpy(), True)
+    close(out, ref_out, RTOL, ATOL, "out")
+    dcon = (ref["dB"] if const_b else ref["dC"]).sum(axis=(0, 3))
+    dvar = (ref["dC"] if const_b else ref["dB"]).sum(axis=1)
+    assert t[3].grad.shape == t[3].shape and t[4].grad.shape == t[4].shape
+    sc = lambda a: max(1.0, float(np.abs(a).max()))
+    close(t[3 if const_b else 4].grad, dcon, 1e-3, 2e-3 * sc(dcon), "d const")
+    close(t[4 if const_b else 3].grad, dvar, 1e-3, 2e-3 * sc(dvar), "d var")
