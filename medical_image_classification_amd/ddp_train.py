@@ -1,7 +1,9 @@
 """Data-parallel training -- counterpart of the reference's ddp_train.py (ddp_train.py:64-202): one process per
 GPU, `init_process_group('nccl')` (= RCCL over xGMI on ROCm), DistributedSampler-style sharding of the batch
-stream, DistributedDataParallel with bucketed gradient all-reduce overlapped with backward, rank-0 checkpoints
-`{epoch, model, optimizer, best_acc}` and `--resume`.  Synthetic data replaces ImageFolder.
+stream, gradient all-reduce overlapped with backward (default: `FlatGradDataParallel`, a few large slices of one flat
+buffer launched from backward hooks; `MEDSCAN_DDP=torch`: torch's DistributedDataParallel reducer as the reference wraps
+its model), a synthetic validation pass per epoch, rank-0 checkpoints `{epoch, model, optimizer, best_acc}` written when
+the validation accuracy improves, and `--resume`.  Synthetic data replaces ImageFolder.
 
 Deliberate fixes relative to the reference: LOCAL_RANK is read from the environment
 (the reference leaves `--local_rank` at 0, so under torchrun every rank picks cuda:0, ddp_train.py:56,74-75), and
@@ -40,21 +42,33 @@ def setup_distributed(backend=None):
 
 
 class FlatGradDataParallel(nn.Module):
-    """Data-parallel wrapper with ONE gradient all-reduce per step over a flat fp32 buffer.
+    """Data-parallel wrapper: the gradients live in ONE flat fp32 buffer that is all-reduced in a few large slices,
+    each launched from backward as soon as its last gradient exists -- overlapped with the rest of backward like the
+    reference's DDP reducer (ddp_train.py:134), without that reducer's per-parameter cost.
 
-    torch's DDP reducer pays per parameter: every backward it copies each of the 355 gradients into its bucket (a launch
-    each; autograd hands over freshly allocated gradient tensors, so `gradient_as_bucket_view` cannot avoid it), runs its
-    hooks and bucket bookkeeping, and broadcasts the BatchNorm buffers before every forward.  Measured on one MI355X with a
-    one-rank process group (MEDSCAN_FORCE_DDP=1): 27.1 ms per step against 24.9 ms without the wrapper -- an 8 % tax that
-    every N > 1 run would pay before a byte crosses xGMI.  MedMamba-T has only 57.8 MB of gradients (about 0.5 ms of
-    all-reduce on the xGMI mesh), so here: after backward the gradients are packed into one flat buffer with a multi-tensor
-    copy (a handful of launches), all-reduced ONCE (RCCL picks its own chunking for a message this size), scaled by
-    1/world, and handed to the optimizer as views of that buffer.  Same result as DDP (mean of the ranks' gradients).
-    Parameters and buffers are broadcast from rank 0 at construction, as DDP does; BatchNorm running statistics then stay
-    rank-local (they never enter the training arithmetic; `sync_buffers()` puts rank 0's on every rank -- ddp_train.main
-    calls it before each checkpoint -- which is the state torch DDP's per-forward broadcast converges to)."""
+    torch's DDP pays per parameter: every backward it copies each of the 355 gradients into its bucket (a launch each;
+    autograd hands over freshly allocated gradient tensors, so `gradient_as_bucket_view` cannot avoid it), runs its hooks and
+    bucket bookkeeping, and broadcasts the BatchNorm buffers before every forward.  Measured on one MI355X with a ONE-rank
+    process group (MEDSCAN_FORCE_DDP=1; nothing here has run on more than one GPU yet): 27.8 ms per step against 24.9 ms
+    without a wrapper, 25.25 ms with this one.
 
-    def __init__(self, module):
+    * The flat buffer is cut into `n_slices` contiguous slices at parameter boundaries (registration order = forward order,
+      so backward completes them last slice first).  A post-accumulate hook per parameter counts its slice down; when a
+      slice is complete its gradients are packed with one multi-tensor copy and `all_reduce(async_op=True)` is issued:
+      RCCL runs it on its own stream behind the copy while backward continues on the compute stream.
+    * Collectives must be issued in the same order on every rank: slices go out strictly last -> first.  A slice that is
+      not complete when its turn comes (a parameter unused on THIS rank this step never fires its hook) holds back the ones
+      before it; `reduce_gradients()` -- called between backward() and optimizer.step() (train.train_step does) -- issues
+      whatever is left in the same order, waits for all of them and scales by 1 / world.
+    * Unused parameters: a parameter contributes zeros where its gradient is None, and one flag per parameter travels at the
+      end of the flat buffer: a parameter that ANY rank used gets the averaged gradient on EVERY rank (as under torch DDP);
+      only a parameter unused everywhere keeps `grad = None`.  Without the flags the ranks that did not use it would skip
+      its optimizer update and the replicas would drift apart silently.
+    * Parameters and buffers are broadcast from rank 0 at construction, as DDP does; BatchNorm running statistics then stay
+      rank-local (they never enter the training arithmetic; `sync_buffers()` puts rank 0's on every rank -- ddp_train.main
+      calls it before each checkpoint / validation -- which is the state torch DDP's per-forward broadcast converges to)."""
+
+    def __init__(self, module, n_slices=4):
         super().__init__()
         self.module = module
         self.world = dist.get_world_size()
@@ -62,8 +76,27 @@ class FlatGradDataParallel(nn.Module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params or any(p.dtype != torch.float32 or p.device != self.params[0].device for p in self.params):
             raise RuntimeError("FlatGradDataParallel needs fp32 parameters on one device (use MEDSCAN_DDP=torch otherwise)")
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=self.params[0].device, dtype=torch.float32)
-        self.views = [v.view_as(p) for v, p in zip(self.flat.split([p.numel() for p in self.params]), self.params)]
+        sizes = [p.numel() for p in self.params]
+        total, P = sum(sizes), len(self.params)
+        # [gradients | one "used" flag per parameter]
+        self.flat = torch.zeros(total + P, device=self.params[0].device, dtype=torch.float32)
+        self.views = [v.view_as(p) for v, p in zip(self.flat[:total].split(sizes), self.params)]
+        self.flags = self.flat[total:]
+        # contiguous slices of about equal size, cut at parameter boundaries
+        n_slices = max(1, min(int(os.environ.get("MEDSCAN_DDP_SLICES", n_slices)), P))
+        self.slice_of, self.slices, acc, lo, first = [], [], 0, 0, 0
+        for i, n in enumerate(sizes):
+            self.slice_of.append(len(self.slices))
+            acc += n
+            if acc >= total * (len(self.slices) + 1) / n_slices or i == P - 1:
+                self.slices.append((first, i + 1, lo, acc))          # parameters [first, i+1), flat elements [lo, acc)
+                first, lo = i + 1, acc
+        self._left = [0] * len(self.slices)
+        self._next = len(self.slices) - 1                            # next slice to go out (last -> first)
+        self._works = []
+        self._armed = False
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     @staticmethod
     def _broadcast(tensors, src=0):
@@ -78,6 +111,12 @@ class FlatGradDataParallel(nn.Module):
                 t.copy_(f)
 
     def forward(self, *args, **kwargs):
+        # arm the slice counters for the backward of this forward (training only)
+        if torch.is_grad_enabled() and self.module.training:
+            self._left = [hi - lo for lo, hi, _, _ in self.slices]
+            self._next = len(self.slices) - 1
+            self._works = []
+            self._armed = True
         return self.module(*args, **kwargs)
 
     def sync_buffers(self):
@@ -85,27 +124,57 @@ class FlatGradDataParallel(nn.Module):
         if bufs:
             self._broadcast(bufs)
 
-    def reduce_gradients(self):
-        """Call between backward() and optimizer.step(): p.grad <- mean over ranks (train.train_step does)."""
+    def _make_hook(self, i):
+        def hook(_param):
+            if not self._armed:
+                return
+            k = self.slice_of[i]
+            self._left[k] -= 1
+            while self._next >= 0 and self._left[self._next] == 0:      # in order, last slice first
+                self._launch(self._next)
+                self._next -= 1
+        return hook
+
+    def _launch(self, k):
+        """Pack slice k (zeros where this rank has no gradient) and start its all-reduce."""
+        first, last, lo, hi = self.slices[k]
         src, dst, missing = [], [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[first:last], self.views[first:last]):
             if p.grad is None:
-                missing.append(v)                      # (unused this step: contributes zeros, as under DDP)
+                missing.append(v)
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad); dst.append(v)
         if missing:
             torch._foreach_zero_(missing)
         if src:
             torch._foreach_copy_(dst, src)
-        dist.all_reduce(self.flat)
-        self.flat.mul_(1.0 / self.world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is not None:
-                p.grad = v
+        self._works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+
+    def reduce_gradients(self):
+        """Call between backward() and optimizer.step(): p.grad <- mean over ranks (train.train_step does)."""
+        if not self._armed:                 # backward of a forward made without arming (eval / no_grad): plain path
+            self._left = [0] * len(self.slices)
+            self._next = len(self.slices) - 1
+            self._works = []
+        while self._next >= 0:              # slices held back by a parameter this rank did not use
+            self._launch(self._next)
+            self._next -= 1
+        self.flags.copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params]))
+        self._works.append(dist.all_reduce(self.flags, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works, self._armed = [], False
+        total = self.flat.numel() - len(self.params)
+        self.flat[:total].mul_(1.0 / self.world)
+        used = self.flags.tolist()
+        for p, v, f in zip(self.params, self.views, used):
+            if f > 0:
+                p.grad = v                  # used on some rank: every rank steps it with the same averaged gradient
+            # unused everywhere: grad stays None, the optimizer skips it on all ranks alike
 
 
 def wrap_ddp(net, distributed, local_rank, on_cuda=True, broadcast_buffers=True):
-    """The data-parallel wrapper of ddp_train.py:134.  Default: FlatGradDataParallel (one flat all-reduce per step);
+    """The data-parallel wrapper of ddp_train.py:134.  Default: FlatGradDataParallel (sliced flat all-reduce overlapped with backward);
     MEDSCAN_DDP=torch: torch's DistributedDataParallel as the reference uses it (25 MiB buckets overlapped with backward,
     `gradient_as_bucket_view`, buffers broadcast every forward)."""
     if not distributed:
@@ -132,7 +201,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--batch-size", type=int, default=32)
-    ap.add_argument("--local_rank", type=int, default=0)
+    ap.add_argument("--local_rank", type=int, default=None,
+                    help="device index when LOCAL_RANK is not in the environment (torch.distributed.launch style); torchrun's "
+                         "LOCAL_RANK wins")
     ap.add_argument("--steps-per-epoch", type=int, default=10)
     ap.add_argument("--num-classes", type=int, default=8)
     ap.add_argument("--res", type=int, default=224)
@@ -144,6 +215,8 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("ddp_train.py needs MI355X GPUs: the SS2D kernels have no CPU fallback")
+    if args.local_rank is not None and "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = str(args.local_rank)
     distributed, rank, world, local_rank = setup_distributed("nccl")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -169,10 +242,17 @@ def main(argv=None):
             running += loss.item()
         if hasattr(ddp_net, "sync_buffers"):
             ddp_net.sync_buffers()              # rank 0's BatchNorm statistics everywhere before they are saved / evaluated
+        # validation on rank 0 only, as the reference does (ddp_train.py:171-187), on a synthetic batch
         if rank == 0:
-            print(f"[epoch {epoch + 1}] train_loss: {running / args.steps_per_epoch:.3f}")
-            torch.save({"epoch": epoch, "model": net.state_dict(), "optimizer": optimizer.state_dict(),
-                        "best_acc": best_acc}, args.save_path)
+            net.eval()
+            with torch.no_grad():
+                images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
+                acc = (net(images).argmax(dim=1) == labels).sum().item() / args.batch_size
+            print(f"[epoch {epoch + 1}] train_loss: {running / args.steps_per_epoch:.3f}  val_accuracy: {acc:.3f}")
+            if acc >= best_acc:                 # checkpoint on improvement (ddp_train.py:188-194)
+                best_acc = acc
+                torch.save({"epoch": epoch, "model": net.state_dict(), "optimizer": optimizer.state_dict(),
+                            "best_acc": best_acc}, args.save_path)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

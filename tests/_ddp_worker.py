@@ -48,6 +48,7 @@ def main():
     if os.environ.get("MEDSCAN_DDP", "flat") != "torch":
         from medical_image_classification_amd.ddp_train import FlatGradDataParallel
         assert isinstance(ddp, FlatGradDataParallel)
+        assert len(ddp.slices) == 4 and ddp._next == -1, "every slice must have been launched from the backward hooks"
         ddp.reduce_gradients()
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ddp.params, ddp.views))
         with torch.no_grad():                                   # buffers: rank-local until sync_buffers()
@@ -81,6 +82,38 @@ def main():
     gp = [torch.zeros_like(flat_p) for _ in range(world)]
     dist.all_gather(gp, flat_p)
     assert torch.equal(gp[0], gp[1])
+    # (4) a parameter that only ONE rank uses: every rank must step it with the same averaged gradient (torch DDP semantics);
+    #     a parameter nobody uses keeps grad None.  The slices before the unused one are held back on the rank that does not
+    #     use it and go out from reduce_gradients() in the same order as on the other rank.
+    if os.environ.get("MEDSCAN_DDP", "flat") != "torch":
+        class Two(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.a, self.b, self.c, self.never = nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 4)
+
+            def forward(self, x, use_b):
+                x = self.a(x)
+                if use_b:
+                    x = self.b(x)
+                return self.c(x)
+        torch.manual_seed(1)
+        m = Two()
+        w = FlatGradDataParallel(m, n_slices=4)
+        o = torch.optim.SGD(m.parameters(), lr=0.1)
+        x = torch.randn(3, 4, generator=torch.Generator().manual_seed(7 + rank))
+        w.train()
+        w(x, use_b=(rank == 0)).sum().backward()
+        # rank 1 does not use b: its slice (and the ones in front of it) wait for reduce_gradients(); rank 0 has sent all but
+        # the slice of the never-used parameter
+        assert w._next >= 0
+        w.reduce_gradients()
+        assert m.b.weight.grad is not None, "a parameter used on another rank must receive the averaged gradient"
+        assert m.never.weight.grad is None, "a parameter unused everywhere keeps grad None"
+        o.step()
+        fp = torch.cat([p.detach().flatten() for p in m.parameters()])
+        gq = [torch.zeros_like(fp) for _ in range(world)]
+        dist.all_gather(gq, fp)
+        assert torch.equal(gq[0], gq[1]), "replicas diverged after a step with a rank-dependent unused parameter"
     dist.barrier()
     if rank == 0:
         print("DDP_OK", flush=True)
