@@ -136,21 +136,26 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    TileStage<BM, AF32, ATR> ta;
-    TileStage<BN, BF32, BTR> tb;
-    ta.fetch(A, lda, m0, kbeg, M, kend, tid);
-    tb.fetch(B, ldb, n0, kbeg, N, kend, tid);
-    const int fr = lane & 15, fq = lane >> 4;
+    // register staging two k-steps deep: the loads of steps k+1 and k+2 are in flight while step k is multiplied (with
+    // K <= 128 -- in_proj / x_proj of the first stages -- the whole operand is requested before the first MFMA)
     using TA = TileStage<BM, AF32, ATR>;
     using TB = TileStage<BN, BF32, BTR>;
-    for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+    TA ta[2];
+    TB tb[2];
+    ta[0].fetch(A, lda, m0, kbeg, M, kend, tid);
+    tb[0].fetch(B, ldb, n0, kbeg, N, kend, tid);
+    if (kbeg + kBK < kend) {
+        ta[1].fetch(A, lda, m0, kbeg + kBK, M, kend, tid);
+        tb[1].fetch(B, ldb, n0, kbeg + kBK, N, kend, tid);
+    }
+    auto step = [&](TA &sa_, TB &sb_, int k0) {          // stage set (sa_, sb_) holds k-step k0
         __syncthreads();                                 // the previous k-step's fragments have been read
-        ta.put(sA, tid);
-        tb.put(sB, tid);
+        sa_.put(sA, tid);
+        sb_.put(sB, tid);
         __syncthreads();
-        if (k0 + kBK < kend) {                          // next k-step: in flight during the MFMAs below
-            ta.fetch(A, lda, m0, k0 + kBK, M, kend, tid);
-            tb.fetch(B, ldb, n0, k0 + kBK, N, kend, tid);
+        if (k0 + 2 * kBK < kend) {                      // refill this set with k-step k0 + 2
+            sa_.fetch(A, lda, m0, k0 + 2 * kBK, M, kend, tid);
+            sb_.fetch(B, ldb, n0, k0 + 2 * kBK, N, kend, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < kBK / 32; ++ks) {
@@ -165,6 +170,11 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[b], acc[a][b], 0, 0, 0);
             }
         }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * kBK) {
+        step(ta[0], tb[0], k0);
+        if (k0 + kBK < kend) step(ta[1], tb[1], k0 + kBK);
     }
     // D[i][j]: i = n within the tile (row 4*fq + r of the accumulator), j = m within the tile (column fr)
 #pragma unroll

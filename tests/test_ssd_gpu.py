@@ -421,3 +421,51 @@ def test_ssd_all_direction_forward_launch_matches_four_launches(cfg, monkeypatch
     close(du1, du0, 1e-4, "du")
     for k in p0:
         close(p1[k], p0[k], 1e-4, k)
+
+
+def _fusion_224_inputs():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fusion_loss_224.npz"))
+    torch.manual_seed(int(g["seed"]))                         # the reference-run script's generator (tools/make_golden_fusion.py)
+    vis, ir = torch.rand(1, 3, 224, 224), torch.rand(1, 3, 224, 224)
+    assert abs(vis.double().sum().item() - float(g["vis_sum"])) < 1e-6 and abs(ir.double().sum().item() - float(g["ir_sum"])) < 1e-6
+    return g, vis, ir
+
+
+def test_fusion_loss_224_on_gpu_matches_reference_vectors():
+    """FusionLoss forward + backward ON THE GPU at 224 x 224 (BASELINE.json configs[4]; the size at which MIOpen's backward of
+    the reference's single-channel 11x11 conv2d chain faulted) against vectors from running the reference's
+    loss.py on CPU (tests/golden/fusion_loss_224.npz): every loss term and d total / d fused image."""
+    from medical_image_classification_amd.fusion_loss import FusionLoss
+    g, vis, ir = _fusion_224_inputs()
+    gen = torch.from_numpy(g["gen"]).to(dev()).requires_grad_()
+    total, loss_in, ssim_value, loss_grad = FusionLoss().to(dev())(vis.to(dev()), ir.to(dev()), gen)
+    total.backward()
+    torch.cuda.synchronize()
+    for name, v in (("total", total), ("loss_in", loss_in), ("ssim_value", ssim_value), ("loss_grad", loss_grad)):
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[name], rtol=1e-4, atol=1e-5, err_msg=name)
+    ref = g["dgen"]
+    np.testing.assert_allclose(gen.grad.cpu().numpy(), ref, rtol=1e-3, atol=2e-4 * float(np.abs(ref).max()))
+
+
+def test_vfefm_fusion_step_at_224():
+    """One bf16-autocast fusion_step of the model CrossMamba/train.py:80-91 builds at BASELINE.json configs[4]'s image size
+    (2 x 3 x 224 x 224 pairs, batch 1): finite loss terms, a finite gradient on every used parameter, weights move."""
+    from medical_image_classification_amd.train_fusion import build_fusion_model, fusion_step, synthetic_pair
+    from medical_image_classification_amd.fusion_loss import FusionLoss
+    from medical_image_classification_amd.train import make_adam
+    torch.manual_seed(0)
+    net = build_fusion_model().to(dev()).train()
+    opt = make_adam(net.parameters(), lr=2e-4)
+    vis, ir = synthetic_pair(1, 224, dev())
+    before = net.final_conv.weight.detach().clone()
+    terms = fusion_step(net, opt, FusionLoss().to(dev()), vis, ir, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).item() for t in terms)
+    used = 0
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all().item(), n
+            used += 1
+    assert used > 1000
+    assert not torch.equal(before, net.final_conv.weight.detach())
