@@ -50,23 +50,50 @@ __device__ __forceinline__ void bn_block_combine(float a, float b, int ct, int c
     }
 }
 
-// pass 1 forward: sums of (x - pivot) and (x - pivot)^2 per channel, pivot = running_mean (conditioning)
+// pixels block `bx` of `nblk` visits: rows bx*rpi + r0 + k*nblk*rpi < npix, r0 < rpi
+__device__ __forceinline__ float bn_block_count(int bx, int nblk, int rpi, int64_t npix) {
+    const int64_t stride = (int64_t)nblk * rpi;
+    int64_t n = 0;
+    for (int r0 = 0; r0 < rpi; ++r0) {
+        const int64_t start = (int64_t)bx * rpi + r0;
+        if (start < npix) n += (npix - start - 1) / stride + 1;
+    }
+    return (float)n;
+}
+
+// pass 1 forward: per block and channel (mean_b, M2_b = sum (x - mean_b)^2) of the pixels the block visits, accumulated
+// around a DATA-derived pivot (the channel's value at the block's first pixel): one-pass sums of x - pivot and
+// (x - pivot)^2 lose no digits however far the channel's mean is from zero -- a pivot of running_mean (0 after a reset)
+// cancelled catastrophically for |mean| >> std.  The finalize kernel merges the blocks with Chan's parallel formula.
 template <typename T>
 __global__ void __launch_bounds__(kBnThreads)
-bn_stats_kernel(const T *__restrict__ x, int64_t xps, const float *__restrict__ pivot, const float *__restrict__ shift,
-                float *__restrict__ part, int64_t npix, int C,
-                int ct, int rpi) {
+bn_stats_kernel(const T *__restrict__ x, int64_t xps, float *__restrict__ part, int64_t npix, int C, int ct, int rpi) {
     const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
     const bool cv = c < C;
-    const float pv = cv ? pivot[c] - (shift ? shift[c] : 0.0f) : 0.0f;      // pivot for x = pivot for (x + shift) - shift
+    const int64_t pfirst = (int64_t)blockIdx.x * rpi;
+    const float pv = (cv && pfirst < npix) ? bn_ld(x + pfirst * xps + c) : 0.0f;
     float s1 = 0.0f, s2 = 0.0f;
     if (cv) {
-        for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
+        for (int64_t p = pfirst + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
             const float v = bn_ld(x + p * xps + c) - pv;
             s1 += v; s2 = fmaf(v, v, s2);
         }
     }
-    bn_block_combine(s1, s2, ct, c, cv, part, C);
+    // block totals of (x - pv), (x - pv)^2 -> (mean_b, M2_b); the per-thread partials share the block's pivot, so they add
+    __shared__ float red[2][kBnThreads];
+    red[0][t] = s1; red[1][t] = s2;
+    __syncthreads();
+    for (int s = kBnThreads / 2; s >= ct; s >>= 1) {
+        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+        __syncthreads();
+    }
+    if (t < ct && cv) {
+        const float nb = bn_block_count(blockIdx.x, gridDim.x, rpi, npix);
+        const float m = nb > 0.0f ? red[0][t] / nb : 0.0f;
+        float *row = part + (int64_t)blockIdx.x * 2 * C;
+        row[c] = pv + m;                                               // mean_b
+        row[C + c] = fmaxf(red[1][t] - red[0][t] * m, 0.0f);           // M2_b = S2 - S1^2 / n_b
+    }
 }
 
 // Finalize blocks: 1024 threads = 16 channels x 64 row-slots; slot k adds partial rows k, k+64, ... (<= 16 loads in a
@@ -86,21 +113,36 @@ __device__ __forceinline__ void bn_sum_partials(const float *part, int nblk, int
     a = red[0][t % kFinCh]; b = red[1][t % kFinCh];
 }
 
-// finalize forward: batch mean / rstd (saved for apply and backward) and the running-statistics update
+// finalize forward: Chan's merge of the per-block (n_b, mean_b, M2_b): mean = sum n_b mean_b / N, M2 = sum M2_b + n_b (mean_b - mean)^2;
+// batch mean / rstd (saved for apply and backward) and the running-statistics update
 __global__ void __launch_bounds__(kFinCh * kFinSlots)
-bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, const float *__restrict__ shift,
+bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, int rpi, const float *__restrict__ shift,
                        float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt, float momentum, float eps,
                        float *__restrict__ save_mean, float *__restrict__ save_rstd, int64_t npix, int C) {
-    const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
+    __shared__ float red[2][kFinCh * kFinSlots];
+    const int t = threadIdx.x, slot = t / kFinCh;
+    const int c = blockIdx.x * kFinCh + t % kFinCh;
     const bool cv = c < C;
-    float s1, s2;
-    bn_sum_partials(part, nblk, C, c, cv, s1, s2);
+    // pass 1: mean
+    float sa = 0.0f;
+    if (cv) for (int k = slot; k < nblk; k += kFinSlots) sa = fmaf(bn_block_count(k, nblk, rpi, npix), part[(int64_t)k * 2 * C + c], sa);
+    red[0][t] = sa;
+    __syncthreads();
+    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) { if (t < s) red[0][t] += red[0][t + s]; __syncthreads(); }
+    const float mean = red[0][t % kFinCh] / (float)npix;
+    __syncthreads();
+    // pass 2: M2
+    float sb = 0.0f;
+    if (cv) for (int k = slot; k < nblk; k += kFinSlots) {
+        const float dm = part[(int64_t)k * 2 * C + c] - mean;
+        sb += part[(int64_t)k * 2 * C + C + c] + bn_block_count(k, nblk, rpi, npix) * dm * dm;
+    }
+    red[1][t] = sb;
+    __syncthreads();
+    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) { if (t < s) red[1][t] += red[1][t + s]; __syncthreads(); }
     if (cv && threadIdx.x < kFinCh) {
-        const float inv_n = 1.0f / (float)npix;
-        const float m1 = s1 * inv_n;                                  // E[x - pivot], pivot = running_mean
-        const float var = fmaxf(s2 * inv_n - m1 * m1, 0.0f);          // biased variance
+        const float var = fmaxf(red[1][t] / (float)npix, 0.0f);       // biased variance
         const float sh = shift ? shift[c] : 0.0f;                      // the layer's logical input is x + shift
-        const float mean = running_mean[c] - sh + m1;                 // batch mean of x
         save_mean[c] = mean; save_rstd[c] = rsqrtf(var + eps);
         const float unb = npix > 1 ? var * ((float)npix / (float)(npix - 1)) : var;
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (mean + sh);
@@ -194,9 +236,9 @@ int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, 
     const unsigned nblk = bn_blocks(npix, g.rows_per_iter);
     const dim3 grid(nblk, (unsigned)g.ncb), block(kBnThreads);
     using bf = unsigned short;
-    if (x_bf16) hipLaunchKernelGGL((bn_stats_kernel<bf>), grid, block, 0, s, (const bf *)x, xps, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
-    else        hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, 0, s, (const float *)x, xps, running_mean, shift, scratch, npix, C, g.ct, g.rows_per_iter);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, shift, running_mean, running_var, nbt,
+    if (x_bf16) hipLaunchKernelGGL((bn_stats_kernel<bf>), grid, block, 0, s, (const bf *)x, xps, scratch, npix, C, g.ct, g.rows_per_iter);
+    else        hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, 0, s, (const float *)x, xps, scratch, npix, C, g.ct, g.rows_per_iter);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, g.rows_per_iter, shift, running_mean, running_var, nbt,
                        momentum, eps, save_mean, save_rstd, npix, C);
 #define MS_BN_APPLY(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), grid, block, 0, s, (const TI *)x, xps, gamma, beta, save_mean, save_rstd, \
         relu, (TO *)y, npix, C, g.ct, g.rows_per_iter)

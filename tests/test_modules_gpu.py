@@ -777,3 +777,28 @@ def test_scan_fused_dt_projection_forward(cfg):
     sc = float(np.abs(outs[0][0]).max())
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=0, atol=2e-5 * sc)       # fp32 sum order of the R products only
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=0, atol=2e-5 * float(np.abs(outs[0][1]).max()))
+
+
+def test_batchnorm_statistics_with_a_large_mean():
+    """Channels whose mean is ~1e3 x their standard deviation, running_mean at its reset value 0: the batch variance must not
+    lose digits to cancellation (per-block data-derived pivot + Chan's merge in bn_relu.hip).  save_rstd (through y), the
+    running statistics and dx against F.batch_norm in float64."""
+    from medical_image_classification_amd.block_ops import batchnorm_relu
+    B, C, H, W = 8, 48, 28, 28
+    torch.manual_seed(21)
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev()).train()
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev()).double().train()
+    mean = (torch.randn(C, device=dev()) * 300 + 1000).view(1, C, 1, 1)
+    x = (torch.randn(B, C, H, W, device=dev()) + mean).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, C, H, W, device=dev()).contiguous(memory_format=torch.channels_last)
+    xd = x.clone().requires_grad_()
+    yd = batchnorm_relu(bn, xd, False)
+    yd.backward(g)
+    xr = x.double().requires_grad_()
+    yr = ref(xr)
+    yr.backward(g.double())
+    # y = (x - mean) * rstd: an fp32 x near 1e3 carries ~6e-5 of absolute error itself, i.e. ~1e-4 of the unit-variance output
+    assert float((yd.double() - yr).abs().max()) <= 5e-4
+    assert float((bn.running_var.double() - ref.running_var).abs().max()) <= 2e-4 * float(ref.running_var.abs().max())
+    assert float((bn.running_mean.double() - ref.running_mean).abs().max()) <= 1e-6 * float(ref.running_mean.abs().max())
+    assert float((xd.grad.double() - xr.grad).abs().max()) <= 2e-3 * float(xr.grad.abs().max())
