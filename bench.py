@@ -31,6 +31,13 @@ import torch.distributed as dist
 import torch.nn as nn
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+# The scan kernels' second ceiling: vector-instruction issue.  Measured on MI355X (tools/microbench/valu_rate.hip,
+# profiles/r02_valu_rate.txt): one wave64 VALU instruction occupies a SIMD for 4.3 cycles (v_fma_f32, v_mul_f32, v_pk_*_f32
+# alike), v_exp_f32 for 8.2; 1024 SIMDs; 2.4 GHz is the chip's maximum clock (under these kernels it holds ~1.6 GHz).
+# Wave-level VALU instructions per (channel, state, position) element of the shipped kernels, counted in their ISA
+# (tools/kernel_mix.py): per 32-position chunk of an 8-channel x 16-state wave (64 lanes x 64 elements).
+VALU_CYCLES_PER_INSTR, N_SIMD, MAX_CLOCK_HZ = 4.3, 1024, 2.4e9
+VALU_INSTR_PER_STATE_ELEM = {"scan_bwd": 1711 / 64.0, "scan_fwd": 484 / 64.0}
 
 
 def parse():
@@ -74,6 +81,18 @@ WORKLOADS = {"T": "depths/dims/d_state of BASELINE.json configs[1]",
              "SSD": "CNN_Mamba.VSSM defaults, the SSD/Mamba-2 variant the reference's train.py imports"}
 
 
+def valu_ceiling(kind, k):
+    """Issue-bound floor of the kernel: state elements / 64 lanes x instructions per element x cycles per instruction over
+    all SIMDs at the maximum clock, next to the measured time -- the HBM fraction cannot exceed frac / busy_at_max_clock."""
+    elems, ipe = k.get("state_elems", 0), VALU_INSTR_PER_STATE_ELEM.get(kind)
+    if not elems or not ipe:
+        return None
+    floor_ms = elems / 64.0 * ipe * VALU_CYCLES_PER_INSTR / (N_SIMD * MAX_CLOCK_HZ) * 1e3
+    return {"instr_per_state_element": round(ipe, 2), "cycles_per_instr": VALU_CYCLES_PER_INSTR,
+            "issue_floor_ms_per_launch": round(floor_ms / k["launches"], 4),
+            "busy_at_max_clock": round(floor_ms / k["ms"], 3)}
+
+
 def cpu_baseline_worker(args):
     """The same train step on the host: module surface + oracle/ss2d_oracle.py (torch CPU ops + C/OpenMP scan).
     Bounded sample: `cpu_batch` images x (1 warm-up + cpu_steps timed) steps.  Runs in its own process."""
@@ -83,13 +102,14 @@ def cpu_baseline_worker(args):
     from medical_image_classification_amd.train import build_model
     from oracle import ss2d_oracle
     torch.manual_seed(0)
-    net = build_model(num_classes=args.num_classes, variant=args.variant)
+    n_cls = 2                               # BASELINE.json configs[0]: "CPU-only PyTorch train.py on 2 synthetic classes"
+    net = build_model(num_classes=n_cls, variant=args.variant)
     ss2d_oracle.install(net)
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     lossf = nn.CrossEntropyLoss()
     x = torch.randn(args.cpu_batch, 3, args.res, args.res)
-    y = torch.randint(0, args.num_classes, (args.cpu_batch,))
+    y = torch.randint(0, n_cls, (args.cpu_batch,))
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -105,7 +125,7 @@ def cpu_baseline_worker(args):
         step()
     dt = time.perf_counter() - t0
     return {"value": round(args.cpu_batch * args.cpu_steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"MedMamba-{args.variant} fp32 full train step (fwd+bwd+Adam), bs={args.cpu_batch}, "
+            "sample": f"MedMamba-{args.variant} fp32 full train step (fwd+bwd+Adam), 2 classes (BASELINE.json configs[0]), bs={args.cpu_batch}, "
                       f"{args.res}x{args.res}, 1 warm-up + {args.cpu_steps} timed step(s), {dt:.1f} s timed; "
                       "scan = oracle/scan_oracle.c (OpenMP), other ops = torch CPU. The reference's own CPU path "
                       "(Python-loop selective_scan_ref) measured 0.0046 images/s on 8 vCPU (BASELINE.md section 2)."}
@@ -220,6 +240,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 4),
                     "algorithmic_bytes_per_launch": k["bytes"] // k["launches"],
+                    "valu": valu_ceiling(dom, k),
                     "other": {n: {"GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                                   "ms_per_step": round(v["ms"] / args.steps, 3)} for n, v in kern.items()}}
         out = {"metric": f"images/sec MedMamba-{args.variant} 3x{args.res}x{args.res} bs={args.batch_size} train step",
@@ -229,7 +250,8 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"MedMamba-{args.variant} ({WORKLOADS[args.variant]}) full "
                                       f"training step fwd+bwd+Adam, {args.batch_size} x 3x{args.res}x{args.res} per GPU, "
-                                      f"{args.num_classes} classes, random-init weights",
+                                      f"{args.num_classes} classes, random-init weights; ONE resident synthetic batch re-used "
+                                      "every step, no per-step loss.item() host sync (the reference loop has one, train.py:80)",
                           "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                           "loss": round(final_loss, 4)},
                "roofline": roofline}

@@ -50,15 +50,13 @@ __device__ __forceinline__ void bn_block_combine(float a, float b, int ct, int c
     }
 }
 
-// pixels block `bx` of `nblk` visits: rows bx*rpi + r0 + k*nblk*rpi < npix, r0 < rpi
+// pixels block `bx` of `nblk` visits (rows bx*rpi + r0 + k*nblk*rpi < npix, r0 < rpi): every block gets `q` full rounds of
+// rpi rows plus its share of the last, partial round
 __device__ __forceinline__ float bn_block_count(int bx, int nblk, int rpi, int64_t npix) {
-    const int64_t stride = (int64_t)nblk * rpi;
-    int64_t n = 0;
-    for (int r0 = 0; r0 < rpi; ++r0) {
-        const int64_t start = (int64_t)bx * rpi + r0;
-        if (start < npix) n += (npix - start - 1) / stride + 1;
-    }
-    return (float)n;
+    const int64_t per_round = (int64_t)nblk * rpi;
+    const int64_t q = npix / per_round, rem = npix - q * per_round;
+    const int64_t extra = rem - (int64_t)bx * rpi;
+    return (float)(q * rpi + (extra < 0 ? 0 : (extra > rpi ? rpi : extra)));
 }
 
 // pass 1 forward: per block and channel (mean_b, M2_b = sum (x - mean_b)^2) of the pixels the block visits, accumulated
@@ -123,25 +121,27 @@ bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, int rpi, const 
     const int t = threadIdx.x, slot = t / kFinCh;
     const int c = blockIdx.x * kFinCh + t % kFinCh;
     const bool cv = c < C;
-    // pass 1: mean
-    float sa = 0.0f;
-    if (cv) for (int k = slot; k < nblk; k += kFinSlots) sa = fmaf(bn_block_count(k, nblk, rpi, npix), part[(int64_t)k * 2 * C + c], sa);
-    red[0][t] = sa;
-    __syncthreads();
-    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) { if (t < s) red[0][t] += red[0][t + s]; __syncthreads(); }
-    const float mean = red[0][t % kFinCh] / (float)npix;
-    __syncthreads();
-    // pass 2: M2
-    float sb = 0.0f;
+    const int64_t per_round = (int64_t)nblk * rpi;
+    const int64_t q = npix / per_round, rem = npix - q * per_round;
+    auto count = [&](int k) { const int64_t e = rem - (int64_t)k * rpi; return (float)(q * rpi + (e < 0 ? 0 : (e > rpi ? rpi : e))); };
+    // one pass around the pivot p = block 0's mean (block means differ from each other by ~std / sqrt(n_b): no cancellation):
+    //   s0 = sum n_b (mean_b - p),  s1 = sum M2_b + n_b (mean_b - p)^2   ->   mean = p + s0 / N,  M2 = s1 - s0^2 / N
+    const float pvt = cv ? part[c] : 0.0f;
+    float sa = 0.0f, sb = 0.0f;
     if (cv) for (int k = slot; k < nblk; k += kFinSlots) {
-        const float dm = part[(int64_t)k * 2 * C + c] - mean;
-        sb += part[(int64_t)k * 2 * C + C + c] + bn_block_count(k, nblk, rpi, npix) * dm * dm;
+        const float nb = count(k), dm = part[(int64_t)k * 2 * C + c] - pvt;
+        sa = fmaf(nb, dm, sa);
+        sb += fmaf(nb * dm, dm, part[(int64_t)k * 2 * C + C + c]);
     }
-    red[1][t] = sb;
+    red[0][t] = sa; red[1][t] = sb;
     __syncthreads();
-    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) { if (t < s) red[1][t] += red[1][t + s]; __syncthreads(); }
+    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) {
+        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+        __syncthreads();
+    }
+    const float s0 = red[0][t % kFinCh], mean = pvt + s0 / (float)npix;
     if (cv && threadIdx.x < kFinCh) {
-        const float var = fmaxf(red[1][t] / (float)npix, 0.0f);       // biased variance
+        const float var = fmaxf((red[1][t] - s0 * s0 / (float)npix) / (float)npix, 0.0f);       // biased variance
         const float sh = shift ? shift[c] : 0.0f;                      // the layer's logical input is x + shift
         save_mean[c] = mean; save_rstd[c] = rsqrtf(var + eps);
         const float unb = npix > 1 ? var * ((float)npix / (float)(npix - 1)) : var;

@@ -16,6 +16,19 @@
 
 namespace ms {
 
+#ifdef MS_CLOCK
+// diagnostic build only (tools/build_variant.sh clock "scan_ss2d.hip" "-DMS_CLOCK"): the clock the chip holds while the forward
+// kernel runs = sum over waves of (shader cycles, s_memtime) / (100 MHz reference ticks, s_memrealtime) -- MI355X_MICROARCH.md
+// "DVFS give-back" item 6.  The stamps go to a buffer of their own and feed nothing else.
+__device__ unsigned long long ms_clock_acc[2];
+extern "C" int ms_debug_clock(unsigned long long *out, int reset) {
+    unsigned long long z[2] = {0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ms_clock_acc), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ms_clock_acc), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 constexpr int kN = 16;              // d_state of the fast path
 constexpr int kRPs = kN + 4;        // row pitch (floats) of the [position][state] B / C tiles (16-byte aligned rows)
 constexpr int kMaxR = 32;           // largest fused dt_rank
@@ -127,6 +140,9 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
     float4 ru[NEV], rd[NEV], rBC[NBC];
     float rdt[NDT];
     float4 uk[NEV];
+#ifdef MS_CLOCK
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rk0 = __builtin_amdgcn_s_memrealtime();
+#endif
     auto fetch = [&](int ch) {
         const int l0 = ch * kCL;
         int *tab = spos[ch & 1];
@@ -253,6 +269,12 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
         }
         wave_sync();
     }
+#ifdef MS_CLOCK
+    if (lane == 0) {
+        atomicAdd(&ms_clock_acc[0], __builtin_amdgcn_s_memtime() - ck0);
+        atomicAdd(&ms_clock_acc[1], __builtin_amdgcn_s_memrealtime() - rk0);
+    }
+#endif
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

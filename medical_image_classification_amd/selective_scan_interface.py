@@ -28,9 +28,10 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
-        self.records = []          # (kind, algorithmic_bytes, start_event, end_event)
+        self.records = []          # (kind, algorithmic_bytes, state_elements, start_event, end_event)
 
-    def launch(self, kind, nbytes, device, fn):
+    def launch(self, kind, nbytes, device, fn, state_elems=0):
+        """state_elems = batch * dim * seqlen * dstate of the launch (the unit of the kernels' VALU work)."""
         if not self.enabled:
             return fn()
         s = torch.cuda.current_stream(device)
@@ -38,15 +39,15 @@ class KernelTimer:
         e0.record(s)
         rc = fn()
         e1.record(s)
-        self.records.append((kind, nbytes, e0, e1))
+        self.records.append((kind, nbytes, state_elems, e0, e1))
         return rc
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, nbytes, e0, e1 in self.records:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "bytes": 0})
-            d["launches"] += 1; d["ms"] += e0.elapsed_time(e1); d["bytes"] += nbytes
+        for kind, nbytes, elems, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "bytes": 0, "state_elems": 0})
+            d["launches"] += 1; d["ms"] += e0.elapsed_time(e1); d["bytes"] += nbytes; d["state_elems"] += elems
         self.records = []
         return out
 

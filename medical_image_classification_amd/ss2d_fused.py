@@ -86,7 +86,7 @@ def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R, a
     P.A_d_stride, P.A_dstate_stride = N, 1
     P.B_batch_stride, P.B_group_stride, P.B_dstate_stride, P.B_l_stride = L * 4 * C, C, 1, 4 * C
     P.C_batch_stride, P.C_group_stride, P.C_dstate_stride, P.C_l_stride = L * 4 * C, C, 1, 4 * C
-    P.u, P.delta, P.A = xc.data_ptr(), delta.data_ptr(), A.data_ptr()
+    P.u, P.delta, P.A = xc.data_ptr(), (delta.data_ptr() if delta is not None else None), A.data_ptr()
     P.B, P.C = proj.data_ptr() + 4 * R, proj.data_ptr() + 4 * (R + N)
     P.D, P.delta_bias = Ds.data_ptr(), dt_bias.data_ptr()
     P.out = out.data_ptr() if out is not None else None
@@ -330,11 +330,17 @@ class _SS2DInner(torch.autograd.Function):
             else:
                 xm = xc.view(M, D).to(mm_dtype) if mm_dtype is not None else xc.view(M, D)
                 proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())
-            delta = _dtproj_fwd(proj, wdt, B, L, D, R, C)
+            # inference (no gradient wanted): the Delta projection is formed inside the scan kernel (MS_SCAN_DT_FUSED) --
+            # no dt_proj launch, no delta tensor, no saved states.  Training materialises delta: the backward kernel reads it.
+            fuse_dt = (not any(ctx.needs_input_grad)) and N == 16 and R <= 32 and D % 4 == 0
+            delta = None if fuse_dt else _dtproj_fwd(proj, wdt, B, L, D, R, C)
             P = MsScanParams()
             _ss2d_params(P, xc, proj, delta, A, Dv, bias, y4, x_state, H, W, N, R, a_is_log=True)
+            if fuse_dt:
+                P.delta_softplus |= 128             # MS_SCAN_DT_FUSED
+                P.dt_x, P.dt_w, P.dt_rank, P.x = proj.data_ptr(), wdt.data_ptr(), R, None
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), dev,
-                              lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream))
+                              lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream), B * 4 * D * L * N)
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
             _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
                                           beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), M, D, stream),
@@ -384,7 +390,7 @@ class _SS2DInner(torch.autograd.Function):
                                           dy.data_ptr(), dxz.data_ptr() + D * isz, D2, dgamma.data_ptr(), dbeta.data_ptr(),
                                           M, D, stream), "ms_ln_gate_bwd")
             rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * D, L, N, 4, True), dev,
-                              lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream))
+                              lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), stream), B * 4 * D * L * N)
             _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
             dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C)
             # x_proj backward: input gradient in fp32 straight out of the GEMM, split-K weight gradient

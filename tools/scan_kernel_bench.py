@@ -57,6 +57,13 @@ for si in which:
         return e0.elapsed_time(e1) / iters
     tf = run(lib.ms_selective_scan_fwd, P)
     tb = run(lib.ms_selective_scan_bwd, Q)
+    if hasattr(lib, "ms_debug_clock"):           # diagnostic build (-DMS_CLOCK): the clock held during the forward kernel
+        cbuf = (ctypes.c_ulonglong * 2)()
+        torch.cuda.synchronize(); lib.ms_debug_clock(cbuf, 1)
+        for _ in range(20):
+            lib.ms_selective_scan_fwd(ctypes.byref(P), st)
+        torch.cuda.synchronize(); lib.ms_debug_clock(cbuf, 1)
+        print(f"   in-kernel clock of the forward scan: {cbuf[0] / max(1, cbuf[1]) * 0.1:.2f} GHz (s_memtime / s_memrealtime x 100 MHz)")
     if hasattr(lib, "ms_debug_stamps"):          # diagnostic build (-DMS_STAMP): cycles per wave per chunk, by phase
         buf = (ctypes.c_ulonglong * 8)()
         for name, fn, arg, rd in (("fwd", lib.ms_selective_scan_fwd, P, lib.ms_debug_stamps),
