@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 5
+#define MEDSCAN_ABI_VERSION 6
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -88,10 +88,11 @@ typedef enum MsStatus {
                                 (the `dt_projs` einsum, MedMamba.py:400,403-405) while they stage a tile, then add delta_bias
                                 and apply softplus as usual.  dt_x: the dt_rank leading columns of the x_proj rows, addressed
                                 with B's batch / group / l strides (unit stride along r); dt_w (dim, dt_rank) contiguous
-                                (= dt_projs_weight (4, D, R) flattened); dt_rank <= 32; d_state == 16.  Backward: `ddelta`
-                                is NOT written; ddt_x (same addressing as dB, ACCUMULATED with atomics -- zero it first, it is
-                                normally the dts columns of the projection-row gradient whose B | C columns are dB | dC) and
-                                ddt_w (dim, dt_rank) (ACCUMULATED) receive the gradients of the projection instead. */
+                                (= dt_projs_weight (4, D, R) flattened); dt_rank <= 32; d_state == 16; dim % 4 == 0.
+                                FORWARD ONLY in this build: ms_selective_scan_bwd returns MS_ERR_UNSUPPORTED when the flag is
+                                set (the training path materialises delta with ms_dtproj_fwd and back-propagates with
+                                ms_dtproj_bwd); MsScanBwdParams.ddt_x / ddt_w are reserved for that backward (same addressing
+                                as dB / (dim, dt_rank), accumulated) and are ignored today. */
 
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;
@@ -126,7 +127,7 @@ typedef struct MsScanBwdParams {
     int64_t dC_batch_stride, dC_group_stride, dC_dstate_stride, dC_l_stride;
     const float *dout;
     float *du, *ddelta, *dA, *dB, *dC, *dD, *ddelta_bias;
-    float *ddt_x, *ddt_w;                   /* MS_SCAN_DT_FUSED gradients (else ignored) */
+    float *ddt_x, *ddt_w;                   /* reserved: MS_SCAN_DT_FUSED gradients (ignored in this build) */
 } MsScanBwdParams;
 
 /* replaces selective_scan_cuda.fwd  (selective_scan.cpp:226-336 -> selective_scan_fwd_kernel.cuh:67-303) */
@@ -215,6 +216,15 @@ int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_i
                       const float *sample_scale, float *out, int64_t npix, int64_t pixels_per_sample, int C, void *stream);
 int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
                       int64_t npix, int64_t pixels_per_sample, int C, void *stream);
+/* The same with the ReLU that ends the conv branch (MedMamba.py:526) folded in: `left` (dtype of dleft) is that ReLU's OUTPUT,
+ * dleft[p, i] = dout[p, 2i] * [left[p, i] > 0] -- the gradient w.r.t. the ReLU's INPUT, no threshold_backward pass. */
+int ms_block_tail_bwd_relu(const float *dout, const float *sample_scale, const void *left, void *dleft, int dleft_is_bf16, void *dx,
+                           int dx_is_bf16, int64_t npix, int64_t pixels_per_sample, int C, void *stream);
+/* Gradient of the block input in one pass (autograd: a concat for `input.chunk(2, -1)`, MedMamba.py:531, plus an add with the
+ * residual edge of :537):  dinput[p, :] = dout[p, :] + cat(dleft[p, :], dright[p, :]);  dout, dinput (npix, C) fp32, the halves
+ * (npix, C/2) contiguous, bf16 or fp32; C % 8 == 0.  dinput may alias dout. */
+int ms_block_head_bwd(const float *dout, const void *dleft, int dleft_is_bf16, const void *dright, int dright_is_bf16, float *dinput,
+                      int64_t npix, int C, void *stream);
 
 /* ---- training-mode BatchNorm2d (+ fused ReLU) of the conv branch (MedMamba.py:517-527, 533-535) ------------------
  * y, dy, dx : (npix, C) contiguous = the memory of an NCHW tensor in channels_last format; bf16 or fp32.
@@ -234,7 +244,7 @@ int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, co
                         int y_is_bf16, float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C,
                         void *stream);
 int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
-                        const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
+                        const float *save_mean, const float *save_rstd, int relu, void *dx, int dx_is_bf16, float *dgamma, float *dbeta,
                         float *scratch, int64_t npix, int C, void *stream);
 int ms_bn_scratch_floats(int C);
 
@@ -287,6 +297,26 @@ int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const fl
  * lda / ldb in elements, multiples of 8 (bf16) / 4 (fp32); A, B 16-byte aligned; ldc in elements. */
 int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
                  void *C, int c_mode, int64_t ldc, int M, int N, int K, int k_splits, void *stream);
+
+/* The same product with the epilogue of a 1x1 convolution (the `nn.Conv2d(dim/2, dim/2, 1)` + `nn.ReLU()` that end the conv
+ * branch, MedMamba.py:525-526, on channels_last activations = rows of C channels): C = [relu](A B^T + bias[column]); c_mode 0 or 1
+ * only, no split-K.  bias (N) fp32 or NULL. */
+int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
+                          void *C, int c_mode, int64_t ldc, int M, int N, int K, const float *bias, int relu, void *stream);
+
+/* ---- bf16 working copies of the fp32 master weights, all in one launch ---------------------------------------------------
+ * What torch.autocast does with one `_to_copy` launch per weight per forward (plus a layout copy per convolution weight on the
+ * NHWC path) around MedMamba.py:517-527 and :284,326.  `desc`: n_tensors descriptors IN DEVICE MEMORY.
+ *   taps <= 1 : dst[e] = bf16(src[e]), e < n
+ *   taps  > 1 : a (O, inner, kh, kw) convolution weight, taps = kh*kw, written in channels_last memory order (O, kh, kw, inner):
+ *               dst[(o*taps + k)*inner + i] = bf16(src[(o*inner + i)*taps + k]),  n = O*inner*taps */
+typedef struct MsCastDesc {
+    const void *src;        /* fp32 */
+    void *dst;              /* bf16 */
+    int64_t n;
+    int32_t inner, taps;
+} MsCastDesc;
+int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream);
 
 /* Diagnostic: one workgroup busy for `cycles` (< 2^32) shader clocks on `stream` -- used to test whether two streams
  * execute concurrently (medmamba.set_branch_streams). */

@@ -11,7 +11,7 @@ All need CUDA (HIP) tensors and raise RuntimeError otherwise -- no CPU fallback.
 """
 import torch
 
-from . import _lib
+from . import _lib, arena, shadow
 
 
 def _stream(t):
@@ -57,7 +57,7 @@ class _LayerNormRows(torch.autograd.Function):
             dout = dout.float()
         dout = dout.contiguous()
         dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-        dgb = torch.zeros((2, D), device=x.device, dtype=torch.float32)
+        dgb = arena.zeros((2, D), x.device)
         with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_layernorm_bwd(x.data_ptr(), ctx.ps, w.data_ptr(), ctx.eps, dout.data_ptr(),
                                                    int(dout.dtype == torch.bfloat16), dx.data_ptr(), dgb[0].data_ptr(),
@@ -73,26 +73,56 @@ def layernorm_rows(x, weight, bias, eps, out_bf16=None):
     return _LayerNormRows.apply(x, weight, bias, eps, bool(out_bf16))
 
 
+class BlockFrame:
+    """Links the two ends of one block's residual frame, `split_halves(input, frame)` and `block_tail(.., input, .., frame=frame)`:
+    the tail's backward parks the residual edge's gradient (`dout` itself) here instead of returning it, and the split's backward
+    -- which autograd runs after both branches -- emits d_input = dout + cat(d_left, d_right) in one pass (ms_block_head_bwd)
+    instead of a concat followed by autograd's accumulation add."""
+    __slots__ = ("dout",)
+
+    def __init__(self):
+        self.dout = None
+
+
 class _SplitHalves(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, frame):
         half = x.shape[-1] // 2
-        ctx.dtype = x.dtype
+        ctx.dtype, ctx.frame = x.dtype, frame
         return x[..., :half], x[..., half:]
 
     @staticmethod
     def backward(ctx, dl, dr):
-        return torch.cat((dl.to(ctx.dtype), dr.to(ctx.dtype)), dim=-1)
+        frame = ctx.frame
+        dout = frame.dout if frame is not None else None
+        if dout is None:
+            return torch.cat((dl.to(ctx.dtype), dr.to(ctx.dtype)), dim=-1), None
+        frame.dout = None
+        C = dout.shape[-1]
+        ok = (ctx.dtype == torch.float32 and C % 8 == 0 and dl.shape[-1] * 2 == C and dl.shape[:-1] == dout.shape[:-1] == dr.shape[:-1]
+              and dl.dtype in (torch.float32, torch.bfloat16) and dr.dtype in (torch.float32, torch.bfloat16))
+        if not ok:
+            return torch.cat((dl.to(ctx.dtype), dr.to(ctx.dtype)), dim=-1) + dout.to(ctx.dtype), None
+        dl, dr = dl.contiguous(), dr.contiguous()
+        dinp = torch.empty_like(dout)
+        with _lib.on_device(dout.device):
+            _lib.check(_lib.lib().ms_block_head_bwd(dout.data_ptr(), dl.data_ptr(), int(dl.dtype == torch.bfloat16), dr.data_ptr(),
+                                                    int(dr.dtype == torch.bfloat16), dinp.data_ptr(), dout.numel() // C, C,
+                                                    _stream(dout)), "ms_block_head_bwd")
+        return dinp, None
 
 
-def split_halves(x):
-    """`x.chunk(2, dim=-1)` (views) whose backward is a single concat."""
-    return _SplitHalves.apply(x)
+def split_halves(x, frame=None):
+    """`x.chunk(2, dim=-1)` (views) whose backward is a single concat -- or, with the `BlockFrame` that is also given to this
+    block's `block_tail`, one pass that adds the residual edge's gradient as well."""
+    return _SplitHalves.apply(x, frame)
 
 
 class _BlockTail(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, left, x, inp, scale):
+    def forward(ctx, left, x, inp, scale, frame, left_relu):
+        """frame: BlockFrame shared with split_halves(inp, frame) or None.  left_relu: `left` is the output of the ReLU that ends
+        the conv branch and its producer expects the gradient w.r.t. that ReLU's INPUT (conv1x1_relu(.., premasked=True))."""
         _lib.require_cuda(left, x, inp)
         B, H, W, C = inp.shape
         half = C // 2
@@ -112,7 +142,8 @@ class _BlockTail(torch.autograd.Function):
                                                     int(x.dtype == torch.bfloat16), inp.data_ptr(),
                                                     sc.data_ptr() if sc is not None else None, out.data_ptr(),
                                                     B * H * W, H * W, C, _stream(inp)), "ms_block_tail_fwd")
-        ctx.scale, ctx.ldt, ctx.xdt = sc, left.dtype, x.dtype
+        ctx.scale, ctx.ldt, ctx.xdt, ctx.frame = sc, left.dtype, x.dtype, frame
+        ctx.left = left if left_relu else None          # (kept by the ReLU's producer anyway: no extra memory)
         return out
 
     @staticmethod
@@ -123,15 +154,24 @@ class _BlockTail(torch.autograd.Function):
         dx = torch.empty((B, H, W, C // 2), device=dout.device, dtype=ctx.xdt)
         sc = ctx.scale
         with _lib.on_device(dout.device):
-            _lib.check(_lib.lib().ms_block_tail_bwd(dout.data_ptr(), sc.data_ptr() if sc is not None else None, dl.data_ptr(),
-                                                    int(ctx.ldt == torch.bfloat16), dx.data_ptr(), int(ctx.xdt == torch.bfloat16),
-                                                    B * H * W, H * W, C, _stream(dout)), "ms_block_tail_bwd")
-        return dl, dx, dout, None
+            if ctx.left is not None:
+                _lib.check(_lib.lib().ms_block_tail_bwd_relu(dout.data_ptr(), sc.data_ptr() if sc is not None else None,
+                                                             ctx.left.data_ptr(), dl.data_ptr(), int(ctx.ldt == torch.bfloat16),
+                                                             dx.data_ptr(), int(ctx.xdt == torch.bfloat16), B * H * W, H * W, C,
+                                                             _stream(dout)), "ms_block_tail_bwd_relu")
+            else:
+                _lib.check(_lib.lib().ms_block_tail_bwd(dout.data_ptr(), sc.data_ptr() if sc is not None else None, dl.data_ptr(),
+                                                        int(ctx.ldt == torch.bfloat16), dx.data_ptr(), int(ctx.xdt == torch.bfloat16),
+                                                        B * H * W, H * W, C, _stream(dout)), "ms_block_tail_bwd")
+        if ctx.frame is not None and ctx.needs_input_grad[2]:
+            ctx.frame.dout = dout                        # added to cat(d_left, d_right) by the split's backward, in one pass
+            return dl, dx, None, None, None, None
+        return dl, dx, dout, None, None, None
 
 
-def block_tail(left, x, inp, sample_scale=None):
+def block_tail(left, x, inp, sample_scale=None, frame=None, left_relu=False):
     """channel_shuffle(cat(left, sample_scale * x), groups=2) + inp for channel-last (B,H,W,C/2) halves and a (B,H,W,C) input."""
-    return _BlockTail.apply(left, x, inp, sample_scale)
+    return _BlockTail.apply(left, x, inp, sample_scale, frame, left_relu)
 
 
 # ---- training-mode BatchNorm2d (+ ReLU) of the conv branch, channels_last ---------------------------------------------
@@ -194,15 +234,15 @@ class _BatchNormReLU(torch.autograd.Function):
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty_like(dy, memory_format=torch.channels_last)
+        dx = torch.empty(dy.shape, device=dy.device, dtype=x.dtype, memory_format=torch.channels_last)   # written in x's dtype: no cast pass
         dgb = torch.empty((2, C), device=x.device, dtype=torch.float32)
         with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_bn_relu_nhwc_bwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), ctx.ps, dy.data_ptr(), int(dy.dtype == torch.bfloat16), w.data_ptr(),
-                b.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), dx.data_ptr(), dgb[0].data_ptr(),
-                dgb[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(), B * H * W, C, _stream(x)), "ms_bn_relu_nhwc_bwd")
-        dshift = torch.zeros_like(ctx.shift_like) if ctx.shift_like is not None else None      # d/d(shift) of BN(x + shift) == 0
-        return dx.to(x.dtype), dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None, None, None, None, None, None, dshift
+                b.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), dx.data_ptr(), int(dx.dtype == torch.bfloat16),
+                dgb[0].data_ptr(), dgb[1].data_ptr(), _bn_scratch(x.device, C).data_ptr(), B * H * W, C, _stream(x)), "ms_bn_relu_nhwc_bwd")
+        dshift = arena.zeros_like(ctx.shift_like) if ctx.shift_like is not None else None      # d/d(shift) of BN(x + shift) == 0
+        return dx, dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None, None, None, None, None, None, dshift
 
 
 def batchnorm_relu(bn, x, relu, shift=None):
@@ -219,20 +259,111 @@ def batchnorm_relu(bn, x, relu, shift=None):
                                 bn.eps, relu, out_bf16, shift)
 
 
-def conv_branch(seq, x):
+class _ConvShadow(torch.autograd.Function):
+    """conv2d (groups 1, no bias) of a bf16 channels_last activation with the cached bf16 channels_last copy of an fp32 weight
+    (shadow.bf16): no per-use weight cast / layout copy in forward; the weight gradient leaves as ONE fp32 contiguous tensor
+    (autograd's chain was: bf16 channels_last dW -> strided cast to fp32 -> a second, layout-fixing copy inside AccumulateGrad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, dilation):
+        wb = shadow.bf16(weight, conv=True)
+        y = torch.ops.aten.convolution(x, wb, None, stride, padding, dilation, False, [0, 0], 1)
+        ctx.save_for_backward(x, wb)
+        ctx.geom = (stride, padding, dilation)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        stride, padding, dilation = ctx.geom
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, wb, None, stride, padding, dilation, False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        if dw is not None:
+            dw = dw.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        return dx, dw, None, None, None
+
+
+def _conv2d(conv, x):
+    """conv(x) without bias: through the weight's cached bf16 copy under bf16 autocast (see _ConvShadow), F.conv2d otherwise."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.float32 and conv.groups == 1
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        with torch.autocast(device_type="cuda", enabled=False):
+            return _ConvShadow.apply(x, conv.weight, list(conv.stride), list(conv.padding), list(conv.dilation))
+    return torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+class _Conv1x1ReLU(torch.autograd.Function):
+    """relu(conv1x1(x) + bias) on a channels_last activation = one GEMM over the pixel rows with a bias + ReLU epilogue
+    (ms_gemm_bf16_bias_act; MedMamba.py:525-526).  Backward: dz = dy * [y > 0] (or dy itself when the consumer -- block_tail with
+    left_relu -- has already applied the mask), dx = dz W (ms_gemm_bf16), dW = dz^T x (split-K inside the kernel, fp32),
+    dbias = column sums of dz.  The fp32 master weight is read directly (rounded to bf16 while a tile is staged)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, premasked):
+        from .gemm_ops import gemm
+        B, C, H, W = x.shape
+        Co = weight.shape[0]
+        xm = x.permute(0, 2, 3, 1).reshape(B * H * W, C)             # a view: x is channels_last
+        w2 = weight.detach().view(Co, C)
+        y = gemm(xm, w2, out_dtype=torch.bfloat16, bias=bias.detach() if bias is not None else None, relu=True)
+        ctx.save_for_backward(xm, w2, y)
+        ctx.premasked, ctx.shape, ctx.has_bias = premasked, (B, C, H, W), bias is not None
+        return y.view(B, H, W, Co).permute(0, 3, 1, 2)                # NCHW-shaped, channels_last memory
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .gemm_ops import gemm, weight_grad
+        xm, w2, y = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        Co = w2.shape[0]
+        dz = dy.permute(0, 2, 3, 1).reshape(B * H * W, Co)
+        if not ctx.premasked:
+            dz = torch.ops.aten.threshold_backward(dz.contiguous(), y, 0)
+        if dz.dtype not in (torch.bfloat16, torch.float32) or not dz.is_contiguous():
+            dz = dz.contiguous().float()
+        dx = gemm(dz, w2, b_trans=True, out_dtype=xm.dtype) if ctx.needs_input_grad[0] else None
+        dw = weight_grad(dz, xm) if ctx.needs_input_grad[1] else None
+        db = dz.sum(dim=0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return (dx.view(B, H, W, C).permute(0, 3, 1, 2) if dx is not None else None,
+                dw.view(Co, C, 1, 1) if dw is not None else None, db, None)
+
+
+def conv1x1_relu(conv, x, premasked=False):
+    """relu(conv(x)) for a 1x1 nn.Conv2d on a bf16 channels_last CUDA activation through the MFMA GEMM; None if not applicable."""
+    C = conv.in_channels
+    if not (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.float32
+            and C % 8 == 0 and conv.out_channels % 8 == 0 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return None
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _Conv1x1ReLU.apply(x, conv.weight, conv.bias, premasked)
+
+
+def conv_branch(seq, x, premasked_out=False):
     """The conv branch of SS_Conv_SSM (`self.conv33conv33conv11`, MedMamba.py:517-527) applied module by module with each
     BatchNorm2d (+ following ReLU) fused: BN -> conv3x3 -> BN+ReLU -> conv3x3 -> BN+ReLU -> conv1x1 -> ReLU.  Falls back to
-    `seq(x)` when the Sequential is not that exact pattern."""
+    `seq(x)` when the Sequential is not that exact pattern.
+    premasked_out=True returns `(y, masked)`: when `masked`, the backward of `y` expects the gradient w.r.t. the last ReLU's INPUT
+    (its consumer applies the mask: block_tail(.., left_relu=True))."""
     mods = list(seq)
     kinds = [type(m) for m in mods]
     nn = torch.nn
     if kinds != [nn.BatchNorm2d, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.ReLU]:
-        return seq(x.contiguous(memory_format=torch.channels_last))
+        y = seq(x.contiguous(memory_format=torch.channels_last))
+        return (y, False) if premasked_out else y
     x = batchnorm_relu(mods[0], x, False)
     x = _conv_then_bn(mods[1], mods[2], x)
     x = _conv_then_bn(mods[4], mods[5], x)
-    x = mods[7](x)
-    return mods[8](x)
+    y = conv1x1_relu(mods[7], x, premasked=premasked_out)
+    if y is not None:
+        return (y, True) if premasked_out else y
+    y = mods[8](mods[7](x))
+    return (y, False) if premasked_out else y
 
 
 def _conv_then_bn(conv, bn, x):
@@ -244,7 +375,7 @@ def _conv_then_bn(conv, bn, x):
                 and conv.padding_mode == "zeros")
     if not fused_bn:
         return batchnorm_relu(bn, conv(x), True)
-    y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    y = _conv2d(conv, x)
     if not _nhwc_ok(y):
         return batchnorm_relu(bn, y + conv.bias.view(1, -1, 1, 1).to(y.dtype), True)
     return batchnorm_relu(bn, y, True, shift=conv.bias)

@@ -34,8 +34,11 @@ int ln_gate_bwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16,
                          float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
 int block_tail_fwd_dispatch(const void *left, int left_is_bf16, const void *x, int x_is_bf16, const float *input,
                             const float *scale, float *out, int64_t npix, int64_t hw, int C, hipStream_t s);
-int block_tail_bwd_dispatch(const float *dout, const float *scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
+int block_tail_bwd_dispatch(const float *dout, const float *scale, const void *left, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
                             int64_t npix, int64_t hw, int C, hipStream_t s);
+int block_head_bwd_dispatch(const float *dout, const void *dl, int dl_is_bf16, const void *dr, int dr_is_bf16, float *dinp,
+                            int64_t npix, int C, hipStream_t s);
+int cast_bf16_multi_dispatch(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, hipStream_t s);
 int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
                     int out_bf16, int64_t npix, int D, hipStream_t s);
 int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
@@ -48,10 +51,10 @@ int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, 
                     float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C, hipStream_t s);
 int bn_scratch_floats(int C);
 int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int dy_bf16, const float *gamma, const float *beta,
-                    const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
+                    const float *save_mean, const float *save_rstd, int relu, void *dx, int dx_bf16, float *dgamma, float *dbeta,
                     float *scratch, int64_t npix, int C, hipStream_t s);
 int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
-                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, hipStream_t stream);
+                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream);
 }  // namespace ms
 
 extern "C" {
@@ -59,7 +62,22 @@ extern "C" {
 int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
                  void *C, int c_mode, int64_t ldc, int M, int N, int K, int k_splits, void *stream) {
     return ms::gemm_bf16_dispatch(A, a_is_f32, a_trans, lda, B, b_is_f32, b_trans, ldb, C, c_mode, ldc, M, N, K, k_splits,
+                                  nullptr, 0, (hipStream_t)stream);
+}
+
+int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
+                          void *C, int c_mode, int64_t ldc, int M, int N, int K, const float *bias, int relu, void *stream) {
+    return ms::gemm_bf16_dispatch(A, a_is_f32, a_trans, lda, B, b_is_f32, b_trans, ldb, C, c_mode, ldc, M, N, K, 1, bias, relu,
                                   (hipStream_t)stream);
+}
+
+int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream) {
+    return ms::cast_bf16_multi_dispatch(desc, n_tensors, blocks_per_tensor, (hipStream_t)stream);
+}
+
+int ms_block_head_bwd(const float *dout, const void *dleft, int dleft_is_bf16, const void *dright, int dright_is_bf16, float *dinput,
+                      int64_t npix, int C, void *stream) {
+    return ms::block_head_bwd_dispatch(dout, dleft, dleft_is_bf16, dright, dright_is_bf16, dinput, npix, C, (hipStream_t)stream);
 }
 
 int ms_selective_scan_fwd(const MsScanParams *p, void *stream) {
@@ -137,7 +155,14 @@ int ms_block_tail_fwd(const void *left, int left_is_bf16, const void *x, int x_i
 
 int ms_block_tail_bwd(const float *dout, const float *sample_scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
                       int64_t npix, int64_t pixels_per_sample, int C, void *stream) {
-    return ms::block_tail_bwd_dispatch(dout, sample_scale, dleft, dleft_is_bf16, dx, dx_is_bf16, npix, pixels_per_sample, C,
+    return ms::block_tail_bwd_dispatch(dout, sample_scale, nullptr, dleft, dleft_is_bf16, dx, dx_is_bf16, npix, pixels_per_sample, C,
+                                       (hipStream_t)stream);
+}
+
+int ms_block_tail_bwd_relu(const float *dout, const float *sample_scale, const void *left, void *dleft, int dleft_is_bf16, void *dx,
+                           int dx_is_bf16, int64_t npix, int64_t pixels_per_sample, int C, void *stream) {
+    if (!left) return MS_ERR_NULL;
+    return ms::block_tail_bwd_dispatch(dout, sample_scale, left, dleft, dleft_is_bf16, dx, dx_is_bf16, npix, pixels_per_sample, C,
                                        (hipStream_t)stream);
 }
 
@@ -171,9 +196,9 @@ int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, co
 }
 
 int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const void *dy, int dy_is_bf16, const float *gamma, const float *beta,
-                        const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
+                        const float *save_mean, const float *save_rstd, int relu, void *dx, int dx_is_bf16, float *dgamma, float *dbeta,
                         float *scratch, int64_t npix, int C, void *stream) {
-    return ms::bn_bwd_dispatch(x, x_is_bf16, x_pixel_stride, dy, dy_is_bf16, gamma, beta, save_mean, save_rstd, relu, dx, dgamma, dbeta,
+    return ms::bn_bwd_dispatch(x, x_is_bf16, x_pixel_stride, dy, dy_is_bf16, gamma, beta, save_mean, save_rstd, relu, dx, dx_is_bf16, dgamma, dbeta,
                                scratch, npix, C, (hipStream_t)stream);
 }
 

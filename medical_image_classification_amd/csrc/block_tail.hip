@@ -46,9 +46,11 @@ block_tail_fwd_kernel(const TL *__restrict__ left, const TX *__restrict__ x, con
     }
 }
 
+// `left` non-NULL: the left half is the output of a ReLU (the conv branch ends with one, MedMamba.py:526) and its gradient is
+// masked here, dleft = dout * [left > 0], instead of by a threshold_backward pass of its own.
 template <typename TL, typename TX>
 __global__ void __launch_bounds__(256)
-block_tail_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ scale, TL *__restrict__ dleft,
+block_tail_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ scale, const TL *__restrict__ left, TL *__restrict__ dleft,
                       TX *__restrict__ dx, int64_t n4, int c4, int64_t hw) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
@@ -57,8 +59,31 @@ block_tail_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ 
         const int64_t hoff = p * (2 * c4) + 2 * q;
         const float4 g = *reinterpret_cast<const float4 *>(dout + 4 * t);
         const float s = scale ? scale[p / hw] : 1.0f;
-        st2(dleft + hoff, g.x, g.z);
+        float gl0 = g.x, gl1 = g.z;
+        if (left) { const float2 l = ld2(left + hoff); gl0 = l.x > 0.0f ? gl0 : 0.0f; gl1 = l.y > 0.0f ? gl1 : 0.0f; }
+        st2(dleft + hoff, gl0, gl1);
         st2(dx + hoff, s * g.y, s * g.w);
+    }
+}
+
+// Gradient of the block INPUT in one pass: d_input = dout (the residual edge) + cat(d_left_half, d_right_half) (the edge
+// through `input.chunk(2, -1)`).  autograd would run a concat of the two halves and then an add with the residual's
+// gradient: two more round trips over the block's activation.  One thread = 4 consecutive channels of one pixel.
+template <typename TL, typename TR>
+__global__ void __launch_bounds__(256)
+block_head_bwd_kernel(const float *__restrict__ dout, const TL *__restrict__ dl, const TR *__restrict__ dr,
+                      float *__restrict__ dinp, int64_t n4, int c4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int h4 = c4 / 2;                                              // float4 groups per half
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
+        const int64_t p = t / c4;
+        const int q = (int)(t - p * c4);
+        float4 g = *reinterpret_cast<const float4 *>(dout + 4 * t);
+        float2 a, b;
+        if (q < h4) { const TL *s = dl + (p * h4 + q) * 4; a = ld2(s); b = ld2(s + 2); }
+        else        { const TR *s = dr + (p * h4 + (q - h4)) * 4; a = ld2(s); b = ld2(s + 2); }
+        g.x += a.x; g.y += a.y; g.z += b.x; g.w += b.y;
+        *reinterpret_cast<float4 *>(dinp + 4 * t) = g;
     }
 }
 
@@ -86,7 +111,7 @@ int block_tail_fwd_dispatch(const void *left, int left_is_bf16, const void *x, i
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
-int block_tail_bwd_dispatch(const float *dout, const float *scale, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
+int block_tail_bwd_dispatch(const float *dout, const float *scale, const void *left, void *dleft, int dleft_is_bf16, void *dx, int dx_is_bf16,
                             int64_t npix, int64_t hw, int C, hipStream_t s) {
     if (!dout || !dleft || !dx) return MS_ERR_NULL;
     if (npix < 0 || hw <= 0 || C <= 0 || C % 4 != 0 || npix % hw != 0) return MS_ERR_SHAPE;
@@ -95,13 +120,32 @@ int block_tail_bwd_dispatch(const float *dout, const float *scale, void *dleft, 
     const dim3 grid(tail_grid(n4)), block(256);
     using bf = unsigned short;
     if (dleft_is_bf16 && dx_is_bf16)
-        hipLaunchKernelGGL((block_tail_bwd_kernel<bf, bf>), grid, block, 0, s, dout, scale, (bf *)dleft, (bf *)dx, n4, C / 4, hw);
+        hipLaunchKernelGGL((block_tail_bwd_kernel<bf, bf>), grid, block, 0, s, dout, scale, (const bf *)left, (bf *)dleft, (bf *)dx, n4, C / 4, hw);
     else if (dleft_is_bf16)
-        hipLaunchKernelGGL((block_tail_bwd_kernel<bf, float>), grid, block, 0, s, dout, scale, (bf *)dleft, (float *)dx, n4, C / 4, hw);
+        hipLaunchKernelGGL((block_tail_bwd_kernel<bf, float>), grid, block, 0, s, dout, scale, (const bf *)left, (bf *)dleft, (float *)dx, n4, C / 4, hw);
     else if (dx_is_bf16)
-        hipLaunchKernelGGL((block_tail_bwd_kernel<float, bf>), grid, block, 0, s, dout, scale, (float *)dleft, (bf *)dx, n4, C / 4, hw);
+        hipLaunchKernelGGL((block_tail_bwd_kernel<float, bf>), grid, block, 0, s, dout, scale, (const float *)left, (float *)dleft, (bf *)dx, n4, C / 4, hw);
     else
-        hipLaunchKernelGGL((block_tail_bwd_kernel<float, float>), grid, block, 0, s, dout, scale, (float *)dleft, (float *)dx, n4, C / 4, hw);
+        hipLaunchKernelGGL((block_tail_bwd_kernel<float, float>), grid, block, 0, s, dout, scale, (const float *)left, (float *)dleft, (float *)dx, n4, C / 4, hw);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int block_head_bwd_dispatch(const float *dout, const void *dl, int dl_is_bf16, const void *dr, int dr_is_bf16, float *dinp,
+                            int64_t npix, int C, hipStream_t s) {
+    if (!dout || !dl || !dr || !dinp) return MS_ERR_NULL;
+    if (npix < 0 || C <= 0 || C % 8 != 0) return MS_ERR_SHAPE;          // each half is a whole number of 4-channel groups
+    if (npix == 0) return MS_OK;
+    const int64_t n4 = npix * (C / 4);
+    const dim3 grid(tail_grid(n4)), block(256);
+    using bf = unsigned short;
+    if (dl_is_bf16 && dr_is_bf16)
+        hipLaunchKernelGGL((block_head_bwd_kernel<bf, bf>), grid, block, 0, s, dout, (const bf *)dl, (const bf *)dr, dinp, n4, C / 4);
+    else if (dl_is_bf16)
+        hipLaunchKernelGGL((block_head_bwd_kernel<bf, float>), grid, block, 0, s, dout, (const bf *)dl, (const float *)dr, dinp, n4, C / 4);
+    else if (dr_is_bf16)
+        hipLaunchKernelGGL((block_head_bwd_kernel<float, bf>), grid, block, 0, s, dout, (const float *)dl, (const bf *)dr, dinp, n4, C / 4);
+    else
+        hipLaunchKernelGGL((block_head_bwd_kernel<float, float>), grid, block, 0, s, dout, (const float *)dl, (const float *)dr, dinp, n4, C / 4);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

@@ -200,12 +200,12 @@ bn_bwd_reduce_kernel(const T *__restrict__ x, int64_t xps, const TG *__restrict_
 }
 
 // pass 2 backward: dx = gamma * rstd * (dy' - dbeta/n - xhat * dgamma/n)
-template <typename T, typename TG>
+template <typename T, typename TG, typename TD>
 __global__ void __launch_bounds__(kBnThreads)
 bn_bwd_apply_kernel(const T *__restrict__ x, int64_t xps, const TG *__restrict__ dy, const float *__restrict__ gamma,
                     const float *__restrict__ beta, const float *__restrict__ save_mean,
                     const float *__restrict__ save_rstd, int relu, const float *__restrict__ dgamma,
-                    const float *__restrict__ dbeta, TG *__restrict__ dx, int64_t npix, int C, int ct, int rpi) {
+                    const float *__restrict__ dbeta, TD *__restrict__ dx, int64_t npix, int C, int ct, int rpi) {
     const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
     if (c >= C) return;
     const float inv_n = 1.0f / (float)npix;
@@ -249,7 +249,7 @@ int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, 
 }
 
 int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int dy_bf16, const float *gamma, const float *beta,
-                    const float *save_mean, const float *save_rstd, int relu, void *dx, float *dgamma, float *dbeta,
+                    const float *save_mean, const float *save_rstd, int relu, void *dx, int dx_bf16, float *dgamma, float *dbeta,
                     float *scratch, int64_t npix, int C, hipStream_t s) {
     if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !scratch) return MS_ERR_NULL;
     if (npix <= 0 || C <= 0) return npix == 0 && C > 0 ? MS_OK : MS_ERR_SHAPE;
@@ -261,8 +261,10 @@ int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int 
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TG>), grid, block, 0, s, (const TI *)x, xps, (const TG *)dy, gamma, beta, save_mean,      \
                        save_rstd, relu, scratch, npix, C, g.ct, g.rows_per_iter);                                                   \
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinSlots), 0, s, scratch, (int)nblk, dgamma, dbeta, C);            \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TG>), grid, block, 0, s, (const TI *)x, xps, (const TG *)dy, gamma, beta, save_mean,       \
-                       save_rstd, relu, dgamma, dbeta, (TG *)dx, npix, C, g.ct, g.rows_per_iter)
+    if (dx_bf16) hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TG, bf>), grid, block, 0, s, (const TI *)x, xps, (const TG *)dy, gamma, beta, save_mean,       \
+                       save_rstd, relu, dgamma, dbeta, (bf *)dx, npix, C, g.ct, g.rows_per_iter);                                     \
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TG, float>), grid, block, 0, s, (const TI *)x, xps, (const TG *)dy, gamma, beta, save_mean,       \
+                       save_rstd, relu, dgamma, dbeta, (float *)dx, npix, C, g.ct, g.rows_per_iter)
     if (x_bf16 && dy_bf16) { MS_BN_BWD(bf, bf); } else if (x_bf16) { MS_BN_BWD(bf, float); }
     else if (dy_bf16) { MS_BN_BWD(float, bf); } else { MS_BN_BWD(float, float); }
 #undef MS_BN_BWD

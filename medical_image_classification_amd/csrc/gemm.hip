@@ -121,7 +121,8 @@ struct TileStage {
 // columns (TNT = BN / 16 tiles): an activation row block is read once for up to 192 output columns.
 template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR, int CMODE>
 __global__ void __launch_bounds__(256)
-gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int k_per_split) {
+gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int k_per_split,
+                 const float *__restrict__ bias, int relu) {
     constexpr int TNT = BN / 16, MT = BM / 64;
     __shared__ __attribute__((aligned(16))) unsigned short sA[TileStage<BM, AF32, ATR>::kLds];
     __shared__ __attribute__((aligned(16))) unsigned short sB[TileStage<BN, BF32, BTR>::kLds];
@@ -185,7 +186,17 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
         for (int a = 0; a < TNT; ++a) {
             const int n = n0 + a * 16 + fq * 4;
             if (n >= N) continue;
-            const f32x4 v = acc[a][b];
+            f32x4 v = acc[a][b];
+            if (CMODE < 2) {                        // epilogue of the store modes: + bias[column], ReLU (1x1 convolution + bias + ReLU)
+                if (bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += bias[n + r];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
+            }
             if (CMODE == 2) {
                 float *c = static_cast<float *>(C) + (int64_t)m * ldc + n;
 #pragma unroll
@@ -219,20 +230,20 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
 
 template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR>
 static void launch_c(int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B, void *C, int M, int N, int K, int64_t lda,
-                     int64_t ldb, int64_t ldc, int kps) {
+                     int64_t ldb, int64_t ldc, int kps, const float *bias, int relu) {
     switch (c_mode) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 0>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
-        default: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps); break;
+        case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 0>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
+        default: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
     }
 }
 
 template <int BM, int BN>
 static void launch_layout(bool af32, bool bf32, bool atr, bool btr, int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B,
-                          void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int kps) {
+                          void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int kps, const float *bias, int relu) {
 #define MS_GEMM_CASE(AF, BF, AT, BT) \
-    if (af32 == AF && bf32 == BF && atr == AT && btr == BT) { launch_c<BM, BN, AF, BF, AT, BT>(c_mode, grid, s, A, B, C, M, N, K, lda, ldb, ldc, kps); return; }
+    if (af32 == AF && bf32 == BF && atr == AT && btr == BT) { launch_c<BM, BN, AF, BF, AT, BT>(c_mode, grid, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); return; }
     // the combinations the projections use (activations bf16 or fp32, weights fp32)
     MS_GEMM_CASE(false, true, false, false)   // y = x(bf16) W^T
     MS_GEMM_CASE(true, true, false, false)    // y = x(fp32) W^T
@@ -252,8 +263,9 @@ static bool combo_built(bool af32, bool bf32, bool atr, bool btr) {
 }
 
 int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
-                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, hipStream_t stream) {
+                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream) {
     if (!A || !B || !C) return MS_ERR_NULL;
+    if ((bias || relu) && c_mode >= 2) return MS_ERR_SHAPE;          // the epilogue belongs to the store modes
     if (M <= 0 || N <= 0 || K <= 0 || k_splits < 1 || c_mode < 0 || c_mode > 3) return MS_ERR_SHAPE;
     if (k_splits > 1 && c_mode < 2) return MS_ERR_SHAPE;
     if (!combo_built(a_f32, b_f32, a_trans, b_trans)) return MS_ERR_UNSUPPORTED;
@@ -273,7 +285,7 @@ int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const
     const int bm = small ? 64 : 128;
     const dim3 grid((M + bm - 1) / bm, ny, nz);
 #define MS_GEMM_TILE(BM_, BN_) \
-    if (bm == BM_ && bn == BN_) launch_layout<BM_, BN_>(a_f32, b_f32, a_trans, b_trans, c_mode, grid, stream, A, B, C, M, N, K, lda, ldb, ldc, kps);
+    if (bm == BM_ && bn == BN_) launch_layout<BM_, BN_>(a_f32, b_f32, a_trans, b_trans, c_mode, grid, stream, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);
     MS_GEMM_TILE(128, 64) MS_GEMM_TILE(128, 128) MS_GEMM_TILE(128, 192) MS_GEMM_TILE(64, 64) MS_GEMM_TILE(64, 128) MS_GEMM_TILE(64, 192)
 #undef MS_GEMM_TILE
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;

@@ -10,7 +10,7 @@ the stock fp32 GEMMs.  CUDA (HIP) tensors only -- no CPU fallback.
 """
 import torch
 
-from . import _lib
+from . import _lib, arena
 
 
 def _is_f32(t):
@@ -42,7 +42,7 @@ def weight_grad(dy, x, out=None):
     N, K = dy.shape[1], x.shape[1]
     M = dy.shape[0]
     if out is None:
-        out = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+        out = arena.zeros((N, K), dy.device)
     if N >= K:
         return gemm(dy, x, a_trans=True, b_trans=True, out=out, accumulate=True, k_splits=_k_splits(M, _blocks(N, K), N * K))
     # (K x N) orientation, accumulated into the transposed output
@@ -55,9 +55,10 @@ def weight_grad(dy, x, out=None):
     return out
 
 
-def gemm(a, b, a_trans=False, b_trans=False, out=None, out_dtype=torch.float32, accumulate=False, k_splits=1):
+def gemm(a, b, a_trans=False, b_trans=False, out=None, out_dtype=torch.float32, accumulate=False, k_splits=1, bias=None, relu=False):
     """C[i, j] (+)= sum_k Aop[i, k] * Bop[j, k];  a, b: 2-D row-major (unit inner stride) bf16 / fp32 CUDA tensors,
-    Aop = a.T if a_trans else a, Bop = b.T if b_trans else b.  Returns C (M, N) in `out_dtype` (fp32 when accumulating)."""
+    Aop = a.T if a_trans else a, Bop = b.T if b_trans else b.  Returns C (M, N) in `out_dtype` (fp32 when accumulating).
+    bias (N,) fp32 / relu: epilogue C = [relu](.. + bias[j]) of the store modes (ms_gemm_bf16_bias_act)."""
     _lib.require_cuda(a, b)
     if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
         raise RuntimeError("ms_gemm_bf16: 2-D operands with unit inner stride")
@@ -68,7 +69,7 @@ def gemm(a, b, a_trans=False, b_trans=False, out=None, out_dtype=torch.float32, 
     if accumulate or k_splits > 1:
         c_mode = 2
         if out is None:
-            out = torch.zeros((M, N), device=a.device, dtype=torch.float32)
+            out = arena.zeros((M, N), a.device)
     else:
         c_mode = 1 if out_dtype == torch.bfloat16 else 0
         if out is None:
@@ -76,9 +77,19 @@ def gemm(a, b, a_trans=False, b_trans=False, out=None, out_dtype=torch.float32, 
     if out.stride(1) != 1 or tuple(out.shape) != (M, N):
         raise RuntimeError("ms_gemm_bf16: bad output tensor")
     with _lib.on_device(a.device):
-        _lib.check(_lib.lib().ms_gemm_bf16(a.data_ptr(), _is_f32(a), int(a_trans), a.stride(0), b.data_ptr(), _is_f32(b), int(b_trans),
-                                           b.stride(0), out.data_ptr(), c_mode, out.stride(0), M, N, K, int(k_splits),
-                                           _lib.current_stream_ptr(a.device)), "ms_gemm_bf16")
+        if bias is not None or relu:
+            if c_mode == 2:
+                raise RuntimeError("ms_gemm_bf16_bias_act: the epilogue belongs to the store modes (no accumulation / split-K)")
+            if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous() or not bias.is_cuda):
+                raise RuntimeError("ms_gemm_bf16_bias_act: bias must be a contiguous fp32 CUDA vector of N entries")
+            _lib.check(_lib.lib().ms_gemm_bf16_bias_act(a.data_ptr(), _is_f32(a), int(a_trans), a.stride(0), b.data_ptr(), _is_f32(b),
+                                                        int(b_trans), b.stride(0), out.data_ptr(), c_mode, out.stride(0), M, N, K,
+                                                        bias.data_ptr() if bias is not None else None, int(bool(relu)),
+                                                        _lib.current_stream_ptr(a.device)), "ms_gemm_bf16_bias_act")
+        else:
+            _lib.check(_lib.lib().ms_gemm_bf16(a.data_ptr(), _is_f32(a), int(a_trans), a.stride(0), b.data_ptr(), _is_f32(b), int(b_trans),
+                                               b.stride(0), out.data_ptr(), c_mode, out.stride(0), M, N, K, int(k_splits),
+                                               _lib.current_stream_ptr(a.device)), "ms_gemm_bf16")
     return out
 
 

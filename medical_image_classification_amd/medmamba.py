@@ -21,7 +21,8 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
-from .block_ops import block_tail, conv_branch, layernorm_rows, split_halves
+from . import shadow
+from .block_ops import BlockFrame, block_tail, conv_branch, layernorm_rows, split_halves
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate, ss2d_inner
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_splitk
@@ -184,7 +185,9 @@ def fused_block_forward(blk, input):
     """Body of SS_Conv_SSM / SS_Conv_SSD.forward on the fused kernels (MedMamba.py:530-538): halves, in-place LayerNorm of
     the right half -> self_attention, conv branch on the left half (optionally on a side stream: the branches are
     independent until the tail), one-pass concat / shuffle / DropPath / residual tail."""
-    left, right = split_halves(input)
+    # the residual edge's gradient joins the halves' in ONE pass (needs an fp32 input: the frame's kernel is fp32)
+    frame = BlockFrame() if (input.dtype == torch.float32 and input.shape[-1] % 8 == 0 and input.requires_grad) else None
+    left, right = split_halves(input, frame)
     # NCHW view of the strided left half: the branch's first BatchNorm reads it in place (block_ops.batchnorm_relu)
     to_nchw = lambda t: t.permute(0, 3, 1, 2)
     if BRANCH_STREAMS:
@@ -192,14 +195,14 @@ def fused_block_forward(blk, input):
         side = _side_stream(input.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):           # autograd replays the same stream assignment in backward
-            left = conv_branch(blk.conv33conv33conv11, to_nchw(left))
+            left, masked = conv_branch(blk.conv33conv33conv11, to_nchw(left), premasked_out=True)
         x = blk.self_attention(layernorm_rows(right, blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps))
         cur.wait_stream(side)
         left.record_stream(cur)
     else:
         x = blk.self_attention(layernorm_rows(right, blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps))
-        left = conv_branch(blk.conv33conv33conv11, to_nchw(left))
-    return block_tail(left.permute(0, 2, 3, 1), x, input, blk.drop_path.sample_scale(x))
+        left, masked = conv_branch(blk.conv33conv33conv11, to_nchw(left), premasked_out=True)
+    return block_tail(left.permute(0, 2, 3, 1), x, input, blk.drop_path.sample_scale(x), frame=frame, left_relu=masked)
 
 
 class DropPath(nn.Module):
@@ -274,7 +277,9 @@ class PatchMerging2D(nn.Module):
         # order of the four taps as in the reference: (0,0), (1,0), (0,1), (1,1)
         taps = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
         x = torch.cat(taps, dim=-1).view(B, h2, w2, 4 * C)
-        return linear_splitk(_norm_rows(self.norm, x), self.reduction.weight)     # LN lands in the GEMM's dtype
+        # LN lands in the GEMM's dtype; the GEMM writes fp32: the residual stream of the next stage stays fp32 (no cast passes
+        # in front of its LayerNorm / block tail)
+        return linear_splitk(_norm_rows(self.norm, x), self.reduction.weight, out_fp32=x.is_cuda)
 
 
 class SS2D(nn.Module):
@@ -561,6 +566,8 @@ class VSSM(nn.Module):
         return x
 
     def forward(self, x):
+        if self.training and x.is_cuda:
+            shadow.invalidate(x.device)          # one refresh of the bf16 weight copies per training step (one launch)
         x = self.forward_backbone(x)
         x = self.avgpool(x.permute(0, 3, 1, 2))
         return self.head(torch.flatten(x, start_dim=1))

@@ -1,0 +1,114 @@
+"""bf16 working copies ("shadows") of fp32 master parameters, refreshed for the whole model by ONE launch per step.
+
+Under `torch.autocast(bfloat16)` every weight that feeds a MIOpen convolution or a library GEMM is cast per use: one
+`aten::_to_copy` launch per weight per forward (~90 of 4-5 us each for MedMamba-T, MedMamba.py:517-527, 284, 326) plus a layout
+copy per convolution weight on the channels_last path.  `bf16(p)` returns a cached bf16 copy instead; the first request that
+finds its copy stale refreshes ALL registered copies of that device with `ms_cast_bf16_multi` (one grid over a descriptor table
+in device memory; convolution weights are written in channels_last order directly).
+
+A copy is stale when the parameter's version counter or data pointer changed (optimizer steps, `load_state_dict`, `.to()`
+bump / change them) or when `invalidate()` was called since (VSSM.forward does so once per training step, which also covers code
+that writes through `p.data`).  The copies carry no autograd history: the caller's autograd.Function returns the gradient for the
+fp32 master itself.  MEDSCAN_BF16_SHADOWS=0 turns the cache off (every request casts).
+"""
+import ctypes
+import os
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import MsCastDesc
+
+_ENABLED = os.environ.get("MEDSCAN_BF16_SHADOWS", "1") == "1"
+
+
+class _Shadow:
+    __slots__ = ("t", "version", "ptr", "conv", "epoch", "owner")
+
+    def __init__(self, t, conv, owner):
+        self.t, self.version, self.ptr, self.conv, self.epoch, self.owner = t, -1, 0, conv, -1, owner
+
+
+_BY_ID = {}                       # id(parameter) -> _Shadow (entry removed when the parameter dies: nothing is stored ON the parameter,
+                                  # so pickling / deepcopy of a model never sees the cache)
+
+
+class _Registry:
+    def __init__(self):
+        self.params = []          # ids, registration order
+        self.epoch = 0
+        self.table = None         # (key, device tensor holding the descriptors, n, blocks)
+
+
+_REG = {}
+
+
+def _registry(idx):
+    r = _REG.get(idx)
+    if r is None:
+        r = _REG[idx] = _Registry()
+    return r
+
+
+def invalidate(device=None):
+    """Mark every copy (of one device, or of all) stale: the next request refreshes them all in one launch."""
+    for idx, r in _REG.items():
+        if device is None or device.index is None or device.index == idx:
+            r.epoch += 1
+
+
+def _stale(p, sh, epoch):
+    return sh.version != p._version or sh.ptr != p.data_ptr() or sh.epoch != epoch
+
+
+def _refresh(reg, device):
+    live, todo = [], []
+    for pid in reg.params:
+        sh = _BY_ID.get(pid)
+        p = sh.owner() if sh is not None else None
+        if p is None:
+            continue
+        live.append(pid)
+        if p.is_cuda and p.device == device and sh.t.device == device and _stale(p, sh, reg.epoch):
+            todo.append((p, sh))
+    reg.params = live
+    if not todo:
+        return
+    key = tuple((p.data_ptr(), sh.t.data_ptr()) for p, sh in todo)
+    if reg.table is None or reg.table[0] != key:
+        arr = (MsCastDesc * len(todo))()
+        biggest = 1
+        for i, (p, sh) in enumerate(todo):
+            taps = p.shape[2] * p.shape[3] if (sh.conv and p.dim() == 4) else 1
+            arr[i].src, arr[i].dst, arr[i].n = p.data_ptr(), sh.t.data_ptr(), p.numel()
+            arr[i].inner, arr[i].taps = (p.shape[1] if taps > 1 else 1), taps
+            biggest = max(biggest, p.numel())
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        blocks = max(1, min(64, (biggest + 2047) // 2048))
+        reg.table = (key, host.to(device), len(todo), blocks)
+    _, tab, n, blocks = reg.table
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().ms_cast_bf16_multi(tab.data_ptr(), n, blocks, _lib.current_stream_ptr(device)), "ms_cast_bf16_multi")
+    for p, sh in todo:
+        sh.version, sh.ptr, sh.epoch = p._version, p.data_ptr(), reg.epoch
+
+
+def bf16(p, conv=False):
+    """bf16 copy of the fp32 CUDA tensor `p` (a Parameter).  conv=True: `p` is a (O, I, kh, kw) convolution weight and the copy has
+    channels_last strides (what MIOpen's NHWC kernels read).  No autograd history."""
+    if not (_ENABLED and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+        t = p.detach().to(torch.bfloat16)
+        return t.contiguous(memory_format=torch.channels_last) if (conv and p.dim() == 4) else t
+    reg = _registry(p.device.index)
+    pid = id(p)
+    sh = _BY_ID.get(pid)
+    if sh is None or sh.owner() is not p or sh.conv != conv or sh.t.shape != p.shape or sh.t.device != p.device:
+        fmt = torch.channels_last if (conv and p.dim() == 4) else torch.contiguous_format
+        if sh is None or sh.owner() is not p:
+            reg.params.append(pid)
+        sh = _BY_ID[pid] = _Shadow(torch.empty(p.shape, device=p.device, dtype=torch.bfloat16, memory_format=fmt), conv,
+                                   weakref.ref(p, lambda _r, pid=pid: _BY_ID.pop(pid, None)))
+    if _stale(p, sh, reg.epoch):
+        _refresh(reg, p.device)
+    return sh.t

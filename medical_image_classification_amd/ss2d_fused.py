@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, arena
 from ._lib import MsScanBwdParams, MsScanParams
 from .gemm_ops import gemm, weight_grad
 from .selective_scan_interface import TIMER, algorithmic_bytes
@@ -54,8 +54,8 @@ class _DWConvSiLUNHWC(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
         scratch = _dwconv_bwd_scratch(B, C, H, W, x.device)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(b) if b is not None else None
+        dw = arena.zeros_like(w)
+        db = arena.zeros_like(b) if b is not None else None
         with _lib.on_device(x.device):
             _lib.check(_lib.lib().ms_dwconv3x3_silu_nhwc_bwd(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), w.data_ptr(), b.data_ptr() if b is not None else None,
@@ -125,7 +125,7 @@ def _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C):
     The weight gradient reduces over M = B*L with a (D x R) output: split into slices, one batched GEMM, fp32 sum."""
     M = B * L
     if R <= _DT_KERNEL_MAX_RANK:
-        dwdt = torch.zeros_like(wdt)
+        dwdt = arena.zeros_like(wdt)
         _lib.check(_lib.lib().ms_dtproj_bwd(ddelta.data_ptr(), proj.data_ptr(), wdt.data_ptr(), dproj.data_ptr(), dwdt.data_ptr(),
                                             M, D, R, C, _lib.current_stream_ptr(proj.device)), "ms_dtproj_bwd")
         return dwdt
@@ -177,8 +177,8 @@ class _SS2DScan(torch.autograd.Function):
         dy = dy.contiguous().float()                              # (B,L,D): dout of all four directions (group stride 0)
         du4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
         ddelta = torch.empty_like(du4)
-        dproj = torch.zeros_like(proj)
-        dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Ds), torch.zeros_like(dt_bias)
+        dproj = arena.zeros_like(proj)
+        dA, dD, dbias = arena.zeros_like(A), arena.zeros_like(Ds), arena.zeros_like(dt_bias)
         Q = MsScanBwdParams()
         _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R)
         Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
@@ -261,10 +261,10 @@ class _SS2DScanNormGate(torch.autograd.Function):
         dz = torch.empty((B, H, W, D), device=xc.device, dtype=z.dtype)
         du4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
         ddelta = torch.empty_like(du4)
-        dproj = torch.zeros_like(proj)
+        dproj = arena.zeros_like(proj)
         # the small accumulators share one zero-filled buffer (one fill launch instead of five)
         sizes = (A.numel(), Ds.numel(), dt_bias.numel(), gamma.numel(), beta.numel())
-        zbuf = torch.zeros(sum(sizes), device=xc.device, dtype=torch.float32)
+        zbuf = arena.zeros(sum(sizes), xc.device)
         dA, dD, dbias, dgamma, dbeta = (t.view(r.shape) for t, r in zip(zbuf.split(sizes), (A, Ds, dt_bias, gamma, beta)))
         Q = MsScanBwdParams()
         _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R, a_is_log=True)
@@ -368,10 +368,10 @@ class _SS2DInner(torch.autograd.Function):
         dy = torch.empty((B, L, D), device=dev, dtype=torch.float32)
         du4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
         ddelta = torch.empty_like(du4)
-        dproj = torch.zeros_like(proj)
+        dproj = arena.zeros_like(proj)
         scratch = _dwconv_bwd_scratch(B, D, H, W, dev)
         sizes = (A.numel(), Dv.numel(), bias.numel(), gamma.numel(), beta.numel(), cw.numel(), cb.numel() if cb is not None else 0)
-        zbuf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        zbuf = arena.zeros(sum(sizes), dev)
         dA, dD, dbias, dgamma, dbeta, dcw, dcb = zbuf.split(sizes)
         Q = MsScanBwdParams()
         _ss2d_params(Q.f, xc, proj, delta, A, Dv, bias, None, x_state, H, W, N, R, a_is_log=True)
@@ -533,7 +533,7 @@ class _SSDScanMerge(torch.autograd.Function):
         # dA comes back dense, (channel, state of the launch): one accumulator per distinct slice width
         widths = sorted({ns for _, _, ns in _ssd_slices(N)})
         sizes = tuple(4 * Ds * w for w in widths) + (4 * Ds, 4 * Ds)
-        zbuf = torch.zeros(sum(sizes), device=xc.device, dtype=torch.float32)
+        zbuf = arena.zeros(sum(sizes), xc.device)
         *dA_w, dD, dbias = zbuf.split(sizes)
         dA_of = dict(zip(widths, dA_w))
         stream = _lib.current_stream_ptr(xc.device)

@@ -132,7 +132,9 @@ class _LinearSplitK(torch.autograd.Function):
         dt = torch.get_autocast_dtype("cuda") if ac else None
         xm = x.reshape(-1, x.shape[-1])
         if ac:
-            xm, w = xm.to(dt), weight.to(dt)
+            from . import shadow
+            xm = xm.to(dt)
+            w = shadow.bf16(weight) if (dt == torch.bfloat16 and weight.dtype == torch.float32) else weight.detach().to(dt)
         else:
             w = weight
         with torch.autocast(device_type="cuda", enabled=False):
@@ -183,7 +185,7 @@ def linear_splitk(x, weight, out_fp32=False):
         from .gemm_ops import linear_mfma
         with torch.autocast(device_type="cuda", enabled=False):
             return linear_mfma(x, weight, out_fp32)
-    if x.is_cuda and x.numel() // x.shape[-1] >= 8192:
+    if x.is_cuda and (x.numel() // x.shape[-1] >= 8192 or (torch.is_autocast_enabled() and x.requires_grad)):
         return _LinearSplitK.apply(x, weight, out_fp32)
     y = torch.nn.functional.linear(x, weight)
     return y.float() if out_fp32 else y

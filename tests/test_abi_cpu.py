@@ -26,25 +26,27 @@ def test_every_declared_symbol_is_exported(lib):
             "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd"} <= declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in medscan.h but not exported"
-    assert lib.ms_abi_version() == 5
+    assert lib.ms_abi_version() == 6
     assert lib.ms_scan_n_chunks(3136) == 98 and lib.ms_scan_n_chunks(49) == 2 and lib.ms_scan_n_chunks(0) == 0
     assert lib.ms_status_string(-3).decode() == "unsupported state dimension"
 
 
 def test_struct_layout_matches_c(tmp_path):
     """sizeof/offsetof of the ctypes mirrors == what a C compiler sees in medscan.h."""
-    from medical_image_classification_amd._lib import MsScanBwdParams, MsScanParams
+    from medical_image_classification_amd._lib import MsCastDesc, MsScanBwdParams, MsScanParams
     src = tmp_path / "lay.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "medscan.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(MsScanParams),offsetof(MsScanParams,u),offsetof(MsScanParams,x),sizeof(MsScanBwdParams),'
                    'offsetof(MsScanBwdParams,dout),offsetof(MsScanBwdParams,ddelta_bias));'
-                   'printf("%zu %zu %zu\\n",offsetof(MsScanParams,dt_w),offsetof(MsScanParams,dt_rank),offsetof(MsScanBwdParams,ddt_w));return 0;}\n')
+                   'printf("%zu %zu %zu\\n",offsetof(MsScanParams,dt_w),offsetof(MsScanParams,dt_rank),offsetof(MsScanBwdParams,ddt_w));'
+                   'printf("%zu %zu %zu\\n",sizeof(MsCastDesc),offsetof(MsCastDesc,n),offsetof(MsCastDesc,taps));return 0;}\n')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(MsScanParams), MsScanParams.u.offset, MsScanParams.x.offset,
             ctypes.sizeof(MsScanBwdParams), MsScanBwdParams.dout.offset, MsScanBwdParams.ddelta_bias.offset,
-            MsScanParams.dt_w.offset, MsScanParams.dt_rank.offset, MsScanBwdParams.ddt_w.offset]
+            MsScanParams.dt_w.offset, MsScanParams.dt_rank.offset, MsScanBwdParams.ddt_w.offset,
+            ctypes.sizeof(MsCastDesc), MsCastDesc.n.offset, MsCastDesc.taps.offset]
     assert got == want
 
 
