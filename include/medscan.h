@@ -293,7 +293,7 @@ int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const fl
  *   2 or 3 are required when k_splits > 1 (the k range is cut into k_splits slices evaluated by different workgroups: the weight gradient
  *   dW = dy^T x reduces over all B*H*W tokens into an output of a few tiles).
  *   forward  y = x W^T : A = x, B = W;   dx = dy W : A = dy, B = W with b_trans;   dW = dy^T x : A = dy, B = x, both *_trans.
- * Built combinations: (a_trans, b_trans) in {(0,0), (0,1)} with fp32 B (the weight); (1,1) with any dtypes.
+ * Built combinations: (a_trans, b_trans) in {(0,0), (0,1)} with c_mode 0 / 1 (any dtypes); (1,1) with every c_mode and any dtypes.
  * lda / ldb in elements, multiples of 8 (bf16) / 4 (fp32); A, B 16-byte aligned; ldc in elements. */
 int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
                  void *C, int c_mode, int64_t ldc, int M, int N, int K, int k_splits, void *stream);
@@ -317,6 +317,9 @@ typedef struct MsCastDesc {
     int32_t inner, taps;
 } MsCastDesc;
 int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream);
+
+/* Diagnostic: force the workgroup tile of ms_gemm_bf16 (rows 64 / 128, columns 64 / 128 / 192; 0 = the built-in heuristic). */
+int ms_debug_gemm_tile(int block_rows, int block_cols);
 
 /* Diagnostic: one workgroup busy for `cycles` (< 2^32) shader clocks on `stream` -- used to test whether two streams
  * execute concurrently (medmamba.set_branch_streams). */

@@ -38,6 +38,7 @@ int block_tail_bwd_dispatch(const float *dout, const float *scale, const void *l
                             int64_t npix, int64_t hw, int C, hipStream_t s);
 int block_head_bwd_dispatch(const float *dout, const void *dl, int dl_is_bf16, const void *dr, int dr_is_bf16, float *dinp,
                             int64_t npix, int C, hipStream_t s);
+void gemm_debug_tile(int bm, int bn);
 int cast_bf16_multi_dispatch(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, hipStream_t s);
 int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
                     int out_bf16, int64_t npix, int D, hipStream_t s);
@@ -70,6 +71,8 @@ int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda,
     return ms::gemm_bf16_dispatch(A, a_is_f32, a_trans, lda, B, b_is_f32, b_trans, ldb, C, c_mode, ldc, M, N, K, 1, bias, relu,
                                   (hipStream_t)stream);
 }
+
+int ms_debug_gemm_tile(int bm, int bn) { ms::gemm_debug_tile(bm, bn); return MS_OK; }
 
 int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream) {
     return ms::cast_bf16_multi_dispatch(desc, n_tensors, blocks_per_tensor, (hipStream_t)stream);

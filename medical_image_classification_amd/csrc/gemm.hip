@@ -231,11 +231,17 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
 template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR>
 static void launch_c(int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B, void *C, int M, int N, int K, int64_t lda,
                      int64_t ldb, int64_t ldc, int kps, const float *bias, int relu) {
+    // the accumulating modes exist for the weight gradient (both operands transposed) only
+    if constexpr (!(ATR && BTR)) { if (c_mode >= 2) return; }
     switch (c_mode) {
         case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 0>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
         case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
-        default: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
+        default:
+            if constexpr (ATR && BTR) {
+                if (c_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);
+                else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);
+            }
+            break;
     }
 }
 
@@ -245,6 +251,10 @@ static void launch_layout(bool af32, bool bf32, bool atr, bool btr, int c_mode, 
 #define MS_GEMM_CASE(AF, BF, AT, BT) \
     if (af32 == AF && bf32 == BF && atr == AT && btr == BT) { launch_c<BM, BN, AF, BF, AT, BT>(c_mode, grid, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); return; }
     // the combinations the projections use (activations bf16 or fp32, weights fp32)
+    MS_GEMM_CASE(false, false, false, false)  // y = x(bf16) W(bf16 copy)^T
+    MS_GEMM_CASE(true, false, false, false)
+    MS_GEMM_CASE(false, false, false, true)   // dx = dy(bf16) W(bf16 copy)
+    MS_GEMM_CASE(true, false, false, true)
     MS_GEMM_CASE(false, true, false, false)   // y = x(bf16) W^T
     MS_GEMM_CASE(true, true, false, false)    // y = x(fp32) W^T
     MS_GEMM_CASE(false, true, false, true)    // dx = dy(bf16) W
@@ -256,11 +266,13 @@ static void launch_layout(bool af32, bool bf32, bool atr, bool btr, int c_mode, 
 #undef MS_GEMM_CASE
 }
 
-static bool combo_built(bool af32, bool bf32, bool atr, bool btr) {
-    if (!atr && !btr) return bf32;
-    if (!atr && btr) return bf32;
-    return atr && btr;
+static bool combo_built(bool af32, bool bf32, bool atr, bool btr, int c_mode) {
+    if (!atr) return c_mode < 2;              // forward / input gradient: store modes
+    return btr;                               // weight gradient: every mode
 }
+
+static int g_force_bm = 0, g_force_bn = 0;   // experiments (ms_debug_gemm_tile): 0 = the heuristic below
+void gemm_debug_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
 int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
                        int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream) {
@@ -268,21 +280,30 @@ int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const
     if ((bias || relu) && c_mode >= 2) return MS_ERR_SHAPE;          // the epilogue belongs to the store modes
     if (M <= 0 || N <= 0 || K <= 0 || k_splits < 1 || c_mode < 0 || c_mode > 3) return MS_ERR_SHAPE;
     if (k_splits > 1 && c_mode < 2) return MS_ERR_SHAPE;
-    if (!combo_built(a_f32, b_f32, a_trans, b_trans)) return MS_ERR_UNSUPPORTED;
+    if (!combo_built(a_f32, b_f32, a_trans, b_trans, c_mode)) return MS_ERR_UNSUPPORTED;
     // 16-byte pieces: leading dimensions in units of 8 bf16 / 4 fp32, 16-byte aligned bases
     const int64_t ga = a_f32 ? 4 : 8, gb = b_f32 ? 4 : 8;
     if (lda % ga || ldb % gb || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return MS_ERR_STRIDE;
     int kps = (K + k_splits - 1) / k_splits;
     kps = (kps + kBK - 1) / kBK * kBK;
     const int nz = (K + kps - 1) / kps;
-    // column block: the narrowest of 64 / 128 / 192 that covers N in the fewest passes over the rows
-    const int passes = (N + 191) / 192;
-    const int per = (N + passes - 1) / passes;
-    const int bn = per <= 64 ? 64 : per <= 128 ? 128 : 192;
+    // Tile choice, from cold-cache sweeps on MI355X (tools/bench_gemm_cold.py: inside the training step every operand comes from
+    // HBM / MALL, not from a warm L2): 64-column blocks win almost everywhere -- more workgroups in flight hide the load latency,
+    // and the re-read of the A rows per column block is cheap while A is small.  Only when the A operand itself is large
+    // (>= 48 MB: x_proj at stage 0 streams 77 MB of fp32 activations) is it read as few times as possible: the narrowest of
+    // 64 / 128 / 192 that covers N in the fewest passes.
+    const int64_t a_bytes = (int64_t)M * K * (a_f32 ? 4 : 2);
+    int bn = 64;
+    if (!a_trans && a_bytes >= (48ll << 20)) {
+        const int passes = (N + 191) / 192;
+        const int per = (N + passes - 1) / passes;
+        bn = per <= 64 ? 64 : per <= 128 ? 128 : 192;
+    }
+    if (g_force_bn) bn = g_force_bn;
     const int ny = (N + bn - 1) / bn;
-    // row block 64 instead of 128 when 128-row blocks would not fill the chip
-    const bool small = (int64_t)((M + 127) / 128) * ny * nz < 512;
-    const int bm = small ? 64 : 128;
+    // row block 64 instead of 128 when 128-row blocks would not give every CU four workgroups
+    const bool small = (int64_t)((M + 127) / 128) * ny * nz < 1024;
+    const int bm = g_force_bm ? g_force_bm : (small ? 64 : 128);
     const dim3 grid((M + bm - 1) / bm, ny, nz);
 #define MS_GEMM_TILE(BM_, BN_) \
     if (bm == BM_ && bn == BN_) launch_layout<BM_, BN_>(a_f32, b_f32, a_trans, b_trans, c_mode, grid, stream, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);

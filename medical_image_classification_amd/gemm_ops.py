@@ -10,7 +10,7 @@ the stock fp32 GEMMs.  CUDA (HIP) tensors only -- no CPU fallback.
 """
 import torch
 
-from . import _lib, arena
+from . import _lib, arena, shadow
 
 
 def _is_f32(t):
@@ -30,7 +30,8 @@ def _k_splits(k_len, out_blocks, out_elems):
 
 
 def _blocks(rows, cols):
-    """Workgroup tiles ms_gemm_bf16 uses for a (rows x cols) output (128-row blocks, 64/128/192-column blocks)."""
+    """Coarse tile count of a (rows x cols) weight-gradient output (128-row blocks, 64/128/192-column blocks) that the split
+    heuristic below was tuned with; the kernel itself runs 64 x 64 tiles, i.e. ~4x as many workgroups."""
     passes = (cols + 191) // 192
     per = -(-cols // passes)
     bn = 64 if per <= 64 else 128 if per <= 128 else 192
@@ -110,9 +111,10 @@ class _LinearMFMA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, out_fp32):
         xm = _rows(x)
-        w = weight.detach()
-        if w.dtype != torch.float32 or not w.is_contiguous():
-            w = w.float().contiguous()
+        if weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[1] % 8 == 0:
+            w = shadow.bf16(weight)          # cached bf16 copy (one refresh launch per step for all weights): half the cold bytes
+        else:
+            w = weight.detach().float().contiguous()
         y = gemm(xm, w, out_dtype=torch.float32 if out_fp32 else torch.bfloat16)
         ctx.save_for_backward(xm, w)
         ctx.xshape, ctx.xdtype, ctx.wdtype = x.shape, x.dtype, weight.dtype

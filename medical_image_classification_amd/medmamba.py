@@ -260,6 +260,24 @@ class PatchEmbed2D(nn.Module):
         return x if self.norm is None else _norm_rows(self.norm, x, out_bf16=False)
 
 
+class _GatherTaps(torch.autograd.Function):
+    """cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1) for even H, W (MedMamba.py:196-200) as ONE
+    permuting copy each way: every input pixel lands in exactly one tap, so the backward is the inverse permutation (autograd's
+    chain for the four strided slices is 4 zero-fills of the whole activation + 4 strided copies + 3 adds)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        # (B, h2, i, w2, j, C) -> (B, h2, w2, j, i, C): tap t = 2 j + i, the reference's order (0,0), (1,0), (0,1), (1,1)
+        return x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, H // 2, W // 2, 4 * C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h2, w2, C4 = dy.shape
+        C = C4 // 4
+        return dy.view(B, h2, w2, 2, 2, C).permute(0, 1, 4, 2, 3, 5).reshape(B, 2 * h2, 2 * w2, C)
+
+
 class PatchMerging2D(nn.Module):
     """2x2 neighbourhood -> channels, LayerNorm(4C), Linear(4C->2C) (MedMamba.py:172-212)."""
 
@@ -275,8 +293,11 @@ class PatchMerging2D(nn.Module):
         if (W % 2 != 0) or (H % 2 != 0):
             print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
         # order of the four taps as in the reference: (0,0), (1,0), (0,1), (1,1)
-        taps = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
-        x = torch.cat(taps, dim=-1).view(B, h2, w2, 4 * C)
+        if H % 2 == 0 and W % 2 == 0 and x.is_contiguous():
+            x = _GatherTaps.apply(x)
+        else:
+            taps = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+            x = torch.cat(taps, dim=-1).view(B, h2, w2, 4 * C)
         # LN lands in the GEMM's dtype; the GEMM writes fp32: the residual stream of the next stage stays fp32 (no cast passes
         # in front of its LayerNorm / block tail)
         return linear_splitk(_norm_rows(self.norm, x), self.reduction.weight, out_fp32=x.is_cuda)

@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from . import _lib, arena
+from . import _lib, arena, shadow
 from ._lib import MsScanBwdParams, MsScanParams
 from .gemm_ops import gemm, weight_grad
 from .selective_scan_interface import TIMER, algorithmic_bytes
@@ -314,7 +314,10 @@ class _SS2DInner(torch.autograd.Function):
         wdt, A, Dv, bias, gamma, beta = f32(wdt), f32(A_logs), f32(Ds), f32(dt_bias), f32(gamma), f32(beta)
         wx = xproj_w.detach().reshape(4 * C, D)
         mfma = mm_dtype == torch.bfloat16 and _MFMA_GEMM and D % 8 == 0 and M >= _MFMA_MIN_ROWS       # x_proj on ms_gemm_bf16 (fp32 operands read in place)
-        wx = (wx.to(mm_dtype) if (mm_dtype is not None and not mfma) else wx.float()).contiguous()
+        if mfma and xproj_w.dtype == torch.float32 and xproj_w.is_contiguous():
+            wx = shadow.bf16(xproj_w).view(4 * C, D)       # cached bf16 copy, refreshed with all the others by one launch per step
+        else:
+            wx = (wx.to(mm_dtype) if (mm_dtype is not None and not mfma) else wx.float()).contiguous()
         dev = xz.device
         xc = torch.empty((B, H, W, D), device=dev, dtype=torch.float32)
         y4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)

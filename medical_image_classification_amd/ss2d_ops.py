@@ -172,7 +172,7 @@ import os
 # back on the BLAS library (kernel-variant experiments)
 _MFMA_GEMM = os.environ.get("MEDSCAN_MFMA_GEMM", "1") == "1"
 # token-matrix height from which the MFMA kernel is used (below it the library GEMM wins in situ: measured)
-_MFMA_MIN_ROWS = int(os.environ.get("MEDSCAN_MFMA_MIN_ROWS", "32768"))
+_MFMA_MIN_ROWS = int(os.environ.get("MEDSCAN_MFMA_MIN_ROWS", "0"))
 
 
 def linear_splitk(x, weight, out_fp32=False):
