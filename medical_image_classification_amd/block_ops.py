@@ -275,6 +275,7 @@ class _ConvShadow(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wb = ctx.saved_tensors
+        shadow.invalidate(x.device)              # a backward pass is under way: the weights are about to change
         stride, padding, dilation = ctx.geom
         dy = dy.contiguous(memory_format=torch.channels_last)
         if dy.dtype != x.dtype:

@@ -123,6 +123,7 @@ class _LinearMFMA(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xm, w = ctx.saved_tensors
+        shadow.invalidate(xm.device)             # a backward pass is under way: the weights are about to change
         N, K = w.shape
         dym = _rows(dy)
         dx = None

@@ -6,9 +6,11 @@ copy per convolution weight on the channels_last path.  `bf16(p)` returns a cach
 finds its copy stale refreshes ALL registered copies of that device with `ms_cast_bf16_multi` (one grid over a descriptor table
 in device memory; convolution weights are written in channels_last order directly).
 
-A copy is stale when the parameter's version counter or data pointer changed (optimizer steps, `load_state_dict`, `.to()`
-bump / change them) or when `invalidate()` was called since (VSSM.forward does so once per training step, which also covers code
-that writes through `p.data`).  The copies carry no autograd history: the caller's autograd.Function returns the gradient for the
+A copy is stale when the parameter's version counter or data pointer changed (`load_state_dict`, in-place updates under
+no_grad, `.to()` bump / change them) or when `invalidate()` was called since.  The version counter alone is NOT enough: fused
+optimizers (`torch.optim.Adam(fused=True)`) and writes through `p.data` do not bump it -- so every autograd.Function that uses
+a copy calls `invalidate()` from its backward (weights only change after a backward pass), and VSSM.forward does so once per
+training step as well.  The copies carry no autograd history: the caller's autograd.Function returns the gradient for the
 fp32 master itself.  MEDSCAN_BF16_SHADOWS=0 turns the cache off (every request casts).
 """
 import ctypes

@@ -116,7 +116,7 @@ def _dtproj_fwd(proj, wdt, B, L, D, R, C):
         _lib.check(_lib.lib().ms_dtproj_fwd(proj.data_ptr(), wdt.data_ptr(), delta.data_ptr(), M, D, R, C,
                                             _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd")
         return delta
-    dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2).contiguous()                      # (4, M, R)
+    dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2)          # (4, M, R) view: row stride 4C, unit inner stride -- a valid GEMM operand
     return torch.bmm(dts, wdt.transpose(1, 2)).view(4, B, L, D)
 
 
@@ -363,6 +363,7 @@ class _SS2DInner(torch.autograd.Function):
         B, H, W, D2 = xz.shape
         D, L, M, C = D2 // 2, H * W, B * H * W, R + 2 * N
         dev = xz.device
+        shadow.invalidate(dev)                   # a backward pass is under way: the weights are about to change
         isz, xz_bf16 = xz.element_size(), int(xz.dtype == torch.bfloat16)
         if dout.dtype not in (torch.float32, torch.bfloat16):
             dout = dout.float()

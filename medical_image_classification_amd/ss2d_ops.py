@@ -147,6 +147,8 @@ class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xm, w = ctx.saved_tensors
+        from . import shadow
+        shadow.invalidate(xm.device)             # a backward pass is under way: the weights are about to change
         M, K = xm.shape
         N = w.shape[0]
         dym = dy.reshape(M, N).to(xm.dtype)

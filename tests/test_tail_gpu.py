@@ -1,0 +1,266 @@
+"""GPU tests of the launch-tail machinery (round 2): the per-pass zero arena, the one-launch bf16 weight copies, the conv
+branch's shadow-weight convolution and its 1x1 convolution + bias + ReLU on the MFMA GEMM, the one-pass block-input gradient
+(BlockFrame / ms_block_head_bwd), the ReLU mask folded into the block tail's backward, and PatchMerging's tap gather.
+Each fused path is held to the plain torch formulation of the same arithmetic (MedMamba.py:196-200, 517-527, 531-538)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_bf16_weight_copies_one_launch_refresh_and_staleness():
+    from medical_image_classification_amd import shadow
+    torch.manual_seed(0)
+    ps = [nn.Parameter(torch.randn(s, device=dev())) for s in ((48, 48, 3, 3), (192, 96), (96, 96, 1, 1), (7,), (384, 384, 3, 3))]
+    conv = [True, False, True, False, True]
+
+    def want(p, c):
+        t = p.detach().to(torch.bfloat16)
+        return t.contiguous(memory_format=torch.channels_last) if (c and p.dim() == 4) else t
+
+    for p, c in zip(ps, conv):
+        s = shadow.bf16(p, conv=c)
+        assert s.dtype == torch.bfloat16
+        assert s.is_contiguous(memory_format=torch.channels_last) if (c and p.dim() == 4) else s.is_contiguous()
+        assert torch.equal(s, want(p, c))                              # same rounding as torch's cast, channels_last memory order
+    # an in-place update (what an optimizer step is) makes every copy stale; ONE request refreshes them all
+    with torch.no_grad():
+        for p in ps:
+            p.mul_(1.5).add_(0.25)
+    first = shadow.bf16(ps[0], conv=True)
+    reg = shadow._registry(dev().index)
+    tab = reg.table
+    assert tab is not None and tab[2] >= len(ps)                        # the refresh covered (at least) all five in one table
+    for p, c in zip(ps, conv):
+        sh = shadow._BY_ID[id(p)]
+        assert not shadow._stale(p, sh, reg.epoch)
+        assert torch.equal(sh.t, want(p, c))
+    assert first.data_ptr() == shadow.bf16(ps[0], conv=True).data_ptr()        # cached: same tensor
+    # writes through .data do not bump the version counter: invalidate() (VSSM.forward does it once per training step) covers them
+    ps[1].data.add_(1.0)
+    assert not torch.equal(shadow._BY_ID[id(ps[1])].t, want(ps[1], False))
+    shadow.invalidate(dev())
+    assert torch.equal(shadow.bf16(ps[1]), want(ps[1], False))
+    # a fused optimizer step does NOT bump the version counters: the copies are invalidated by the backward of every Function
+    # that used one (here: a convolution through the cached weight), so the step after a backward always refreshes
+    from medical_image_classification_amd.block_ops import _conv2d
+    conv = nn.Conv2d(48, 48, 3, padding=1).to(dev())
+    opt = torch.optim.Adam(conv.parameters(), lr=0.1, fused=True)
+    x = torch.randn(2, 48, 8, 8, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = _conv2d(conv, x)
+            assert torch.equal(y, F.conv2d(x, conv.weight, None, conv.stride, conv.padding))      # the cached copy is current
+        y.float().square().mean().backward()
+        opt.step()
+        opt.zero_grad()
+
+
+def test_conv_with_cached_weight_matches_autocast_conv():
+    from medical_image_classification_amd.block_ops import _conv2d
+    torch.manual_seed(1)
+    conv = nn.Conv2d(48, 48, 3, padding=1).to(dev())
+    x = torch.randn(4, 48, 14, 14, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(4, 48, 14, 14, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = _conv2d(conv, xa)
+        (dxa, dwa) = torch.autograd.grad(ya, (xa, conv.weight), g)
+        yb = F.conv2d(xb, conv.weight, None, conv.stride, conv.padding)
+        (dxb, dwb) = torch.autograd.grad(yb, (xb, conv.weight), g)
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb) and torch.equal(dxa, dxb)
+    assert dwa.dtype == torch.float32 and dwa.is_contiguous()
+    np.testing.assert_allclose(dwa.cpu().numpy(), dwb.cpu().numpy(), rtol=1e-2, atol=2e-2 * float(dwb.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(2, 48, 56, 56), (3, 96, 9, 7), (64, 384, 7, 7)])
+@pytest.mark.parametrize("premasked", [False, True])
+def test_conv1x1_relu_on_the_mfma_gemm(cfg, premasked):
+    """relu(conv1x1(x) + b): forward, dx, dW, db against fp32 torch on the bf16-rounded operands (the kernel rounds the fp32
+    weight to bf16 while staging; accumulation is fp32).  premasked: the caller supplies dy * [y > 0] (block_tail does)."""
+    from medical_image_classification_amd.block_ops import conv1x1_relu
+    B, C, H, W = cfg
+    torch.manual_seed(2)
+    conv = nn.Conv2d(C, C, 1).to(dev())
+    x = torch.randn(B, C, H, W, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    g = torch.randn(B, C, H, W, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv1x1_relu(conv, x, premasked=premasked)
+    assert y is not None and y.dtype == torch.bfloat16 and y.shape == (B, C, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    gin = g * (y > 0) if premasked else g
+    dx, dw, db = torch.autograd.grad(y, (x, conv.weight, conv.bias), gin)
+    xr = x.detach().float().requires_grad_()
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    br = conv.bias.detach().clone().requires_grad_()
+    yr = F.relu(F.conv2d(xr, wr, br))
+    dxr, dwr, dbr = torch.autograd.grad(yr, (xr, wr, br), g.float())
+    tol = lambda t: 1e-2 * float(t.abs().max())
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-2, atol=tol(yr))
+    # the mask is taken from the bf16 output: identical to the fp32 one except where |pre-activation| is below bf16 resolution
+    np.testing.assert_allclose(dx.float().cpu().numpy(), dxr.cpu().numpy(), rtol=2e-2, atol=2 * tol(dxr))
+    np.testing.assert_allclose(dw.cpu().numpy(), dwr.cpu().numpy(), rtol=2e-2, atol=2 * tol(dwr))
+    np.testing.assert_allclose(db.cpu().numpy(), dbr.cpu().numpy(), rtol=2e-2, atol=2 * tol(dbr))
+    assert dw.dtype == torch.float32 and dw.shape == conv.weight.shape
+
+
+@pytest.mark.parametrize("cfg", [(64, 129, 40, True, True), (300, 68, 96, False, True), (257, 48, 48, True, False), (64, 192, 24, False, False)])
+def test_gemm_bias_relu_epilogue(cfg):
+    from medical_image_classification_amd.gemm_ops import gemm
+    M, N, K, bf16_out, relu = cfg
+    if bf16_out and N % 8 != 0:
+        N = (N + 7) // 8 * 8
+    torch.manual_seed(3)
+    a = torch.randn(M, K, device=dev()).to(torch.bfloat16)
+    w = torch.randn(N, K, device=dev())
+    b = torch.randn(N, device=dev())
+    y = gemm(a, w, out_dtype=torch.bfloat16 if bf16_out else torch.float32, bias=b, relu=relu)
+    ref = a.float() @ w.to(torch.bfloat16).float().t() + b
+    if relu:
+        ref = F.relu(ref)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2 if bf16_out else 1e-4,
+                               atol=(1e-2 if bf16_out else 1e-4) * float(ref.abs().max()))
+    with pytest.raises(RuntimeError, match="store modes"):
+        gemm(a, w, bias=b, accumulate=True)
+
+
+@pytest.mark.parametrize("dts", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("shape", [(2, 56, 56, 96), (3, 5, 7, 16), (1, 1, 1, 8)])
+def test_block_frame_gives_the_input_gradient_in_one_pass(shape, dts):
+    """split_halves + block_tail sharing a BlockFrame == the same graph through autograd's concat + accumulation add, bit for bit
+    (two fp32 terms per element: the add is commutative)."""
+    from medical_image_classification_amd.block_ops import BlockFrame, block_tail, split_halves
+    B, H, W, C = shape
+    torch.manual_seed(4)
+    x0 = torch.randn(shape, device=dev())
+    g = torch.randn(shape, device=dev())
+    scale = torch.rand(B, device=dev()) + 0.5
+    grads = []
+    for use_frame in (False, True):
+        x = x0.clone().requires_grad_()
+        frame = BlockFrame() if use_frame else None
+        left, right = split_halves(x, frame)
+        l2 = (left * 1.5).to(dts[0])
+        r2 = torch.tanh(right).to(dts[1])
+        out = block_tail(l2, r2, x, scale, frame=frame)
+        out.backward(g)
+        assert frame is None or frame.dout is None          # consumed
+        grads.append(x.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_block_tail_applies_the_relu_mask_of_its_left_input():
+    from medical_image_classification_amd.block_ops import block_tail
+    torch.manual_seed(5)
+    B, H, W, C = 2, 9, 11, 32
+    z0 = torch.randn(B, H, W, C // 2, device=dev())
+    xr = torch.randn(B, H, W, C // 2, device=dev())
+    inp = torch.randn(B, H, W, C, device=dev())
+    g = torch.randn(B, H, W, C, device=dev())
+    for dt in (torch.float32, torch.bfloat16):
+        z = z0.to(dt).requires_grad_()
+        out = block_tail(F.relu(z), xr, inp)
+        (want,) = torch.autograd.grad(out, z, g)
+        # the fused form: the producer of `left` passes its incoming gradient through unchanged
+        class _Relu(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return F.relu(t)
+
+            @staticmethod
+            def backward(ctx, d):
+                return d
+        z2 = z0.to(dt).requires_grad_()
+        out2 = block_tail(_Relu.apply(z2), xr, inp, left_relu=True)
+        (got,) = torch.autograd.grad(out2, z2, g)
+        assert torch.equal(out, out2) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 6, 5), (64, 56, 56, 96)])
+def test_patch_merging_tap_gather_bit_exact(shape):
+    from medical_image_classification_amd.medmamba import _GatherTaps
+    torch.manual_seed(6)
+    x = torch.randn(shape, device=dev(), requires_grad=True)
+    ref = torch.cat([x[:, i::2, j::2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))], dim=-1)      # MedMamba.py:196-200
+    y = _GatherTaps.apply(x)
+    assert torch.equal(y, ref)
+    g = torch.randn_like(ref)
+    (gr,) = torch.autograd.grad(ref, x, g)
+    (gy,) = torch.autograd.grad(y, x, g)
+    assert torch.equal(gr, gy)
+
+
+def _block_and_input(dim=96, hw=14, batch=4):
+    from medical_image_classification_amd.medmamba import SS_Conv_SSM
+    torch.manual_seed(7)
+    blk = SS_Conv_SSM(hidden_dim=dim, drop_path=0.0, d_state=16).to(dev()).train()
+    x = torch.randn(batch, hw, hw, dim, device=dev())
+    return blk, x
+
+
+def test_grad_arena_passes_do_not_alias(monkeypatch):
+    """Gradients of consecutive backward passes come from different arena buffers: accumulating over two passes without
+    zero_grad gives the sum, and a pass's gradients are not disturbed by the next pass."""
+    from medical_image_classification_amd import arena
+    blk, x = _block_and_input()
+    params = [p for p in blk.parameters() if p.requires_grad]
+
+    def run(xin):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xin.clone().requires_grad_())
+        y.float().square().mean().backward()
+
+    def grads():
+        return [p.grad.clone() if p.grad is not None else None for p in params]
+
+    def zero():
+        for p in params:
+            p.grad = None
+
+    monkeypatch.setattr(arena, "_ENABLED", False)
+    zero(); run(x); ga = grads()
+    zero(); run(2 * x); gb = grads()
+    monkeypatch.setattr(arena, "_ENABLED", True)
+    arena._ARENAS.clear()
+    zero(); run(x)                                  # pass 1 learns the demand (plain torch.zeros)
+    zero(); run(x); g1 = [p.grad for p in params]   # pass 2 runs out of the arena; keep the very tensors autograd stored
+    a = arena._ARENAS[dev().index]
+    assert a.last > 0
+    snap = [t.clone() if t is not None else None for t in g1]
+    run(2 * x)                                      # pass 3 accumulates INTO pass 2's gradients
+    for p, s, u, v in zip(params, snap, ga, gb):
+        if s is None:
+            continue
+        # atomics make the reductions order-dependent in the last bits: compare with a tolerance
+        tol = 1e-3 * max(1e-6, float(u.abs().max()))
+        np.testing.assert_allclose(s.float().cpu().numpy(), u.float().cpu().numpy(), rtol=2e-2, atol=10 * tol)
+        np.testing.assert_allclose(p.grad.float().cpu().numpy(), (u + v).float().cpu().numpy(), rtol=2e-2,
+                                   atol=10 * 1e-3 * max(1e-6, float((u + v).abs().max())))
+
+
+def test_batchnorm_backward_writes_dx_in_the_input_dtype():
+    """x fp32 (the block input's left half), dy bf16 (from the convolution behind it): dx comes out fp32 without a cast pass."""
+    from medical_image_classification_amd.block_ops import batchnorm_relu
+    torch.manual_seed(8)
+    bn = nn.BatchNorm2d(48).to(dev()).train()
+    ref = nn.BatchNorm2d(48).to(dev()).train()
+    x0 = torch.randn(8, 14, 14, 96, device=dev())
+    x = x0.clone().requires_grad_()
+    left = x[..., :48].permute(0, 3, 1, 2)                           # strided NCHW view of the left half
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = batchnorm_relu(bn, left, False)
+    g = torch.randn_like(y)
+    assert y.dtype == torch.bfloat16
+    y.backward(g)
+    xr = x0.clone().requires_grad_()
+    yr = ref(xr[..., :48].permute(0, 3, 1, 2).contiguous())
+    yr.backward(g.float())
+    assert x.grad.dtype == torch.float32
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(xr.grad.abs().max()))
