@@ -24,6 +24,32 @@ namespace ms {
 
 constexpr int kWPB = 4;      // waves per workgroup in the backward: independent except for the per-chunk dB/dC combine
 
+#ifndef MS_BWD_DPP
+#define MS_BWD_DPP 0     // measured: 5.86 vs 5.64 ms per step (the kernel is VALU-issue bound: +13 % VALU costs more than the LDS round trips saved)
+#endif
+// Sum over the wave's 8 channel lanes (lane bits 0-2) of the 8 (position, state) values of a batch, scattered: lane c ends up
+// with the total of v[c].  Pure VALU (DPP row_ror / quad_perm adds + selects, 21 instructions): replaces a transpose through a
+// wave-private LDS tile (16 ds_write_b32 + 4 ds_read_b128 and two dependent LDS round trips per batch and tensor).
+// The lane-bit-2 step needs no select: two DPP adds write disjoint bank sets of one register (banks 0, 2 = lanes with bit 2
+// clear read lane + 4 through row_ror:12; banks 1, 3 read lane - 4 through row_ror:4).  Inline assembly: the builtin only offers
+// the move form.  s_nop 1 = the two wait states a DPP read of a just-written VGPR needs (the compiler's hazard recognizer does
+// not look inside asm blocks).
+__device__ __forceinline__ float xchg_add4_banked(float lo, float hi) {
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float chan_scatter8(const float (&v)[8], int lane) {
+    float a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = xchg_add4_banked(v[q], v[q + 4]);
+    const float b0 = xchg_add<2>(a[0], a[2], lane), b1 = xchg_add<2>(a[1], a[3], lane);
+    return xchg_add<1>(b0, b1, lane);
+}
+
 // SA: scalar decay per channel (A_dstate_stride == 0, the SSD form): one exp2 and one stored decay per position.
 // BCM: the B/C rows and the dB/dC flush follow the pixel order of one fixed direction (MS_SCAN_BC_MAP, see scan_fwd.hip).
 template <int NPL, int CW, int MODE, bool SA = false, bool BCM = false>
@@ -59,6 +85,9 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float *su = su_[wv], *sdl = sdl_[wv], *sg_ = sg__[wv], *sTB = sTB_[wv], *sTC = sTC_[wv], *sbias = sbias_[wv];
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
+    // register (DPP) channel sums: lane (sg, c) owns value c of its group's 8 = position lb + c / 2, state sg * NPL + c % 2
+    constexpr bool kDppSums = MS_BWD_DPP && CW == 8 && NPL == 2;
+    const int t_dpp = (sg * NPL + (c & 1)) * kRowPitch + (c >> 1);
     // transpose-reduce ownership: lane rr sums row rr = (j*NPL + i)*SG + sg' -> position lb + j, state sg'*NPL + i
     const int t_out = ((lane % SG) * NPL + (lane / SG) % NPL) * kRowPitch + lane / (NPL * SG);
 
@@ -279,6 +308,14 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 sg_[lo * kPitch + c] = dd_t;               // d delta' ; the softplus derivative is applied by the store
             }
             if (kb > 0) load_batch(kb - 1);              // next batch's operands: in flight during the transpose below
+            if constexpr (kDppSums) {
+                float vB8[8], vC8[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { vB8[r] = vB[r]; vC8[r] = vC[r]; }
+                sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
+                sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
+                continue;
+            }
             // sums over the wave's CW channels of the per-(position, state) dB / dC terms: transpose through LDS.
             // Lane (sg, c) writes its 4*NPL values into rows (r*SG + sg), column c (64 consecutive floats per r);
             // lane rr then reads row rr (CW consecutive floats), adds them and owns (position, state) = row_of(rr).
