@@ -254,10 +254,14 @@ int ms_bn_scratch_floats(int C);
  * fwd:   delta[k, m, d] = sum_r proj[m, k, r] * Wdt[k, d, r]            (bias and softplus stay inside the scan kernel)
  * bwd:   dproj[m, k, r] (r < R) (+)= sum_d ddelta[k, m, d] * Wdt[k, d, r]   -- written in place into the projection gradient
  *        whose B|C columns ms_selective_scan_bwd fills; dproj must be zero-initialised (shared with that kernel's rule)
- *        dWdt[k, d, r] += sum_m ddelta[k, m, d] * proj[m, k, r]             -- accumulated (zero it first) */
+ *        dWdt[k, d, r] += sum_m ddelta[k, m, d] * proj[m, k, r]             -- accumulated (zero it first)
+ *        `scratch`: ms_dtproj_bwd_scratch_floats(npix, D, R) floats of workspace (need not be initialised) in which the
+ *        workgroups' dWdt partial sums are kept and then added up without atomics; NULL / too small: atomics into dWdt (slower,
+ *        same result up to summation order).  Ranks 1..4 use register-tiled kernels, 5..32 scalar-operand kernels (D % 4 == 0). */
 int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npix, int D, int R, int row_width, void *stream);
-int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
-                  int row_width, void *stream);
+int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, float *scratch,
+                  int64_t scratch_floats, int64_t npix, int D, int R, int row_width, void *stream);
+int64_t ms_dtproj_bwd_scratch_floats(int64_t npix, int D, int R);
 
 /* ---- gated RMS normalisation of the SSD blocks (mamba_ssm 2.2.2 `RMSNormGated`, norm_before_gate=False, one group, as
  * constructed at CNN_Mamba.py:430-431 and applied at :554-555), optionally with the cross-merge sum (:542-552) in front:

@@ -45,8 +45,9 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
 int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
                     float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
 int dtproj_fwd_dispatch(const float *proj, const float *W, float *delta, int64_t npix, int D, int R, int C, hipStream_t s);
-int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, int64_t npix, int D,
-                        int R, int C, hipStream_t s);
+int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, float *scratch,
+                        int64_t scratch_floats, int64_t npix, int D, int R, int C, hipStream_t s);
+int64_t dtproj_bwd_scratch_floats(int64_t npix, int D, int R);
 int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, const float *gamma, const float *beta, float *running_mean,
                     float *running_var, long long *nbt, float momentum, float eps, int relu, void *y, int y_bf16,
                     float *save_mean, float *save_rstd, float *scratch, int64_t npix, int C, hipStream_t s);
@@ -183,10 +184,12 @@ int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npi
     return ms::dtproj_fwd_dispatch(proj, Wdt, delta, npix, D, R, row_width, (hipStream_t)stream);
 }
 
-int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, int64_t npix, int D, int R,
-                  int row_width, void *stream) {
-    return ms::dtproj_bwd_dispatch(ddelta, proj, Wdt, dproj, dWdt, npix, D, R, row_width, (hipStream_t)stream);
+int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, float *scratch,
+                  int64_t scratch_floats, int64_t npix, int D, int R, int row_width, void *stream) {
+    return ms::dtproj_bwd_dispatch(ddelta, proj, Wdt, dproj, dWdt, scratch, scratch_floats, npix, D, R, row_width, (hipStream_t)stream);
 }
+
+int64_t ms_dtproj_bwd_scratch_floats(int64_t npix, int D, int R) { return ms::dtproj_bwd_scratch_floats(npix, D, R); }
 
 int ms_bn_relu_nhwc_fwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, const float *input_shift, const float *gamma, const float *beta,
                         float *running_mean,

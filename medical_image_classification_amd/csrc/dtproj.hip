@@ -167,6 +167,202 @@ dtproj_bwd_kernel(const float *__restrict__ ddelta, const float *__restrict__ pr
     }
 }
 
+// ---- ranks above 4: the same three products with the rank-R operand in SGPRs --------------------------------------------
+// For R = 6..32 the kernels above lose to batched GEMMs (per-pixel LDS transposes, W re-read by every 8-pixel wave).  The small
+// operand of each product is wave-uniform, so it is read with scalar loads and enters v_fma as an SGPR source -- no LDS at all:
+//   forward   lane = channel (VPT slabs of 64): delta[p][d] = sum_r t[p][r] (SGPR) * w[d][r] (VGPR), 64 pixels per wave
+//   dWdt      lane = channel: acc[d][r] += ddelta[p][d] * t[p][r] (SGPR), persistent waves, LDS combine + atomics at the end
+//   ddts      lane = PIXEL: acc[r] += ddelta[p][d] * W[d][r] (SGPR) over the lane's own contiguous ddelta row (16-byte loads);
+//             written in place into the dts columns of the projection-row gradient
+// ddelta is read twice (once per backward product); at these ranks it fits the 256 MB MALL.
+template <int VPT, int RP>
+__global__ void __launch_bounds__(256)
+dtproj_fwd_s_kernel(const float *__restrict__ proj, const float *__restrict__ W, float *__restrict__ delta,
+                    int64_t npix, int D, int R, int C, int ncb, int ppw) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.y / ncb, cb = blockIdx.y % ncb;
+    const int dbase = cb * 64 * VPT;
+    float w[VPT][RP];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int d = dbase + lane + 64 * j;
+#pragma unroll
+        for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
+    }
+    float *dk = delta + (int64_t)k * npix * D + dbase + lane;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * ppw;
+    const int64_t p1 = p0 + ppw < npix ? p0 + ppw : npix;
+#pragma unroll 2
+    for (int64_t p = p0; p < p1; ++p) {
+        const float *row = proj + (p * 4 + k) * C;                  // wave-uniform: scalar loads
+        float t[RP];
+#pragma unroll
+        for (int r = 0; r < RP; ++r) t[r] = row[r];                 // r >= R: B columns of the same row (C >= RP, host-checked), times w = 0
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) a = fmaf(t[r], w[j][r], a);
+            if (dbase + lane + 64 * j < D) dk[p * D + 64 * j] = a;
+        }
+    }
+}
+
+// dWdt: workgroup = 4 waves = 4 slabs of 64*VPT channels sharing tiles of 64 pixels; the tile's dts rows are staged in LDS once
+// (broadcast ds_read_b128: RP/4 reads feed VPT*RP FMAs), ddelta rows are read coalesced 8 pixels ahead.  Persistent over tiles.
+template <int VPT, int RP>
+__global__ void __launch_bounds__(256)
+dtproj_dw_s_kernel(const float *__restrict__ ddelta, const float *__restrict__ proj, float *__restrict__ dW, float *__restrict__ part,
+                   int64_t npix, int D, int R, int C, int ncb) {
+    __shared__ __attribute__((aligned(16))) float sT[64 * RP];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.y / ncb, cb = blockIdx.y % ncb;
+    const int dbase = (cb * 4 + wv) * 64 * VPT;
+    float acc[VPT][RP];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+#pragma unroll
+        for (int r = 0; r < RP; ++r) acc[j][r] = 0.0f;
+    const float *dk = ddelta + (int64_t)k * npix * D;
+    const int64_t ntiles = (npix + 63) / 64;
+    constexpr int PF = 8;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * 64;
+        __syncthreads();                                            // the previous tile's rows have been read
+        for (int idx = threadIdx.x; idx < 64 * RP; idx += 256) {
+            const int px = idx / RP, r = idx - px * RP;
+            const int64_t p = p0 + px;
+            sT[idx] = p < npix ? proj[(p * 4 + k) * C + r] : 0.0f;   // r >= R: in-row values into accumulators never written out
+        }
+        __syncthreads();
+        if (dbase < D) {
+#pragma unroll 1
+            for (int q0 = 0; q0 < 64; q0 += PF) {
+                float g[PF][VPT];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const int64_t p = p0 + q0 + q;
+#pragma unroll
+                    for (int j = 0; j < VPT; ++j) {
+                        const int d = dbase + lane + 64 * j;
+                        g[q][j] = (d < D && p < npix) ? dk[p * D + d] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+#pragma unroll
+                    for (int r4 = 0; r4 < RP / 4; ++r4) {
+                        const float4 t = *reinterpret_cast<const float4 *>(sT + (q0 + q) * RP + 4 * r4);
+#pragma unroll
+                        for (int j = 0; j < VPT; ++j) {
+                            acc[j][4 * r4 + 0] = fmaf(g[q][j], t.x, acc[j][4 * r4 + 0]);
+                            acc[j][4 * r4 + 1] = fmaf(g[q][j], t.y, acc[j][4 * r4 + 1]);
+                            acc[j][4 * r4 + 2] = fmaf(g[q][j], t.z, acc[j][4 * r4 + 2]);
+                            acc[j][4 * r4 + 3] = fmaf(g[q][j], t.w, acc[j][4 * r4 + 3]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // partial sums of this workgroup: one row of `part` per blockIdx.x (summed by dtproj_dw_finalize_kernel -- same-address atomics
+    // from hundreds of workgroups cost 130 us here), or atomics straight into dW when the caller gave no workspace
+    float *dst = part ? part + (int64_t)blockIdx.x * 4 * D * R : dW;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int d = dbase + lane + 64 * j;
+        if (d < D) {
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                if (r < R) {
+                    if (part) dst[((int64_t)k * D + d) * R + r] = acc[j][r];
+                    else atomicAdd(dst + ((int64_t)k * D + d) * R + r, acc[j][r]);
+                }
+            }
+        }
+    }
+}
+
+// dW[i] += sum over the nrows partial rows (dW arrives zero-filled like every accumulated output of this library)
+__global__ void __launch_bounds__(256)
+dtproj_dw_finalize_kernel(const float *__restrict__ part, float *__restrict__ dW, int n, int nrows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= nrows; b += 4) {
+        a0 += part[(int64_t)b * n + i]; a1 += part[(int64_t)(b + 1) * n + i];
+        a2 += part[(int64_t)(b + 2) * n + i]; a3 += part[(int64_t)(b + 3) * n + i];
+    }
+    for (; b < nrows; ++b) a0 += part[(int64_t)b * n + i];
+    dW[i] += (a0 + a1) + (a2 + a3);
+}
+
+// ddts: workgroup = 4 waves = 4 slices of 64 channels over the SAME 64 pixels, lane = pixel: acc[r] += ddelta[p][d] * W[d][r] with
+// the W rows as SGPR operands (scalar loads) over the lane's own contiguous piece of its ddelta row (sixteen 16-byte loads, all in
+// flight before the first FMA); the four partial sums meet in LDS; channels beyond the workgroup's 256 add with atomics (the
+// dts columns of the projection-row gradient arrive zero-filled).  grid (ceil(npix / 64), 4 directions * ceil(D / 256)); D % 4 == 0.
+template <int RP>
+__global__ void __launch_bounds__(256)
+dtproj_dts_s_kernel(const float *__restrict__ ddelta, const float *__restrict__ W, float *__restrict__ dproj,
+                    int64_t npix, int D, int R, int C, int ncg) {
+    __shared__ float sP[4][64][RP + 1];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.y / ncg, cg = blockIdx.y % ncg;
+    const int d_lo = (cg * 4 + wv) * 64;                             // this wave's channel slice [d_lo, d_hi)
+    const int d_hi = d_lo + 64 < D ? d_lo + 64 : D;
+    const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = p < npix;
+    float acc[RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) acc[r] = 0.0f;
+    if (d_lo < D) {
+        const float *grow = ddelta + ((int64_t)k * npix + (live ? p : npix - 1)) * D;
+        const float *Wk = W + (int64_t)k * D * R;
+        float4 g[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            g[i] = d_lo + 4 * i < d_hi ? *reinterpret_cast<const float4 *>(grow + d_lo + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // W rows are read RP wide (r >= R: the next row's leading weights, into accumulators that are never written out); the last
+        // four rows of the whole tensor are read R wide
+        const int d_safe = (k == 3 && d_hi == D) ? d_hi - 4 : d_hi;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                              // fully unrolled: g[] stays in registers
+            const int d0 = d_lo + 4 * i;
+            if (d0 < d_safe) {                                      // wave-uniform
+                const float gv[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *wrow = Wk + (int64_t)(d0 + e) * R; // wave-uniform: scalar loads
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) acc[r] = fmaf(gv[e], wrow[r], acc[r]);
+                }
+            }
+        }
+        if (d_safe < d_hi) {
+            const float4 gl = *reinterpret_cast<const float4 *>(grow + d_safe);
+            const float gv[4] = {gl.x, gl.y, gl.z, gl.w};
+            for (int e = 0; e < 4; ++e) {
+                const float *wrow = Wk + (int64_t)(d_safe + e) * R;
+#pragma unroll
+                for (int r = 0; r < RP; ++r) acc[r] = fmaf(gv[e], (e < 3 || r < R) ? wrow[r] : 0.0f, acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RP; ++r) sP[wv][lane][r] = acc[r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * R; idx += 256) {
+        const int px = idx / R, r = idx - px * R;
+        const int64_t pp = (int64_t)blockIdx.x * 64 + px;
+        if (pp < npix) {
+            const float v = (sP[0][px][r] + sP[1][px][r]) + (sP[2][px][r] + sP[3][px][r]);
+            float *o = dproj + (pp * 4 + k) * C + r;
+            if (ncg == 1) *o = v; else atomicAdd(o, v);
+        }
+    }
+}
+
 // channels per wave: as many 64-channel slabs as keep VPT * RP accumulators <= 128 registers
 static int dt_vpt(int D, int rp) {
     const int need = (D + 63) / 64, cap = 128 / rp;             // rp 4 -> 32, 8 -> 16, 16 -> 8, 32 -> 4
@@ -204,11 +400,58 @@ static int launch_dt(bool bwd, const float *a, const float *proj, const float *W
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
-static int dt_dispatch(bool bwd, const float *a, const float *proj, const float *W, float *o1, float *o2, int64_t npix, int D,
-                       int R, int C, hipStream_t s) {
+// scalar-operand kernels (ranks above 4): RP = R rounded up to a multiple of 4 keeps the unrolled loops tight
+static int64_t dw_workers(int64_t npix, int ncbw) {
+    // dWdt: workgroups of 4 channel slabs, persistent over 64-pixel tiles: about 8 workgroups per CU in total, at least 2 tiles each
+    const int64_t ntiles = (npix + 63) / 64;
+    int64_t bx = (2048 + 4 * ncbw - 1) / (4 * ncbw);
+    if (bx > (ntiles + 1) / 2) bx = (ntiles + 1) / 2;
+    return bx < 1 ? 1 : bx;
+}
+
+template <int RP>
+static int launch_dt_s(bool bwd, const float *a, const float *proj, const float *W, float *o1, float *o2, float *scratch,
+                       int64_t scratch_floats, int64_t npix, int D, int R, int C, hipStream_t s) {
+    const int vpt = (D % 128 == 0 && RP <= 32) ? 2 : 1;
+    const int ncb = (D + 64 * vpt - 1) / (64 * vpt);
+    if (!bwd) {
+        const int ppw = npix >= 32768 ? 64 : 16;                 // few pixels: more, shorter waves
+        const dim3 grid((unsigned)((npix + 4 * ppw - 1) / (4 * ppw)), (unsigned)(4 * ncb));
+        if (vpt == 2) hipLaunchKernelGGL((dtproj_fwd_s_kernel<2, RP>), grid, dim3(256), 0, s, proj, W, o1, npix, D, R, C, ncb, ppw);
+        else          hipLaunchKernelGGL((dtproj_fwd_s_kernel<1, RP>), grid, dim3(256), 0, s, proj, W, o1, npix, D, R, C, ncb, ppw);
+        return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+    }
+    // ddts: 64 pixels x 256 channels per workgroup
+    const int ncg = (D + 255) / 256;
+    hipLaunchKernelGGL((dtproj_dts_s_kernel<RP>), dim3((unsigned)((npix + 63) / 64), (unsigned)(4 * ncg)), dim3(256), 0, s, a, W, o1, npix,
+                       D, R, C, ncg);
+    const int ncbw = (D + 256 * vpt - 1) / (256 * vpt);
+    const int64_t bx = dw_workers(npix, ncbw);
+    const int n = 4 * D * R;
+    float *part = (scratch && scratch_floats >= bx * n) ? scratch : nullptr;
+    const dim3 grid((unsigned)bx, (unsigned)(4 * ncbw));
+    if (vpt == 2) hipLaunchKernelGGL((dtproj_dw_s_kernel<2, RP>), grid, dim3(256), 0, s, a, proj, o2, part, npix, D, R, C, ncbw);
+    else          hipLaunchKernelGGL((dtproj_dw_s_kernel<1, RP>), grid, dim3(256), 0, s, a, proj, o2, part, npix, D, R, C, ncbw);
+    if (part) hipLaunchKernelGGL(dtproj_dw_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, o2, n, (int)bx);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+static int dt_dispatch(bool bwd, const float *a, const float *proj, const float *W, float *o1, float *o2, float *scratch,
+                       int64_t scratch_floats, int64_t npix, int D, int R, int C, hipStream_t s) {
     if (npix < 0 || D <= 0 || R <= 0 || C < R) return MS_ERR_SHAPE;
     if (R > 32) return MS_ERR_SHAPE;                              // dt_rank > 32 (d_model > 512) is not tiled by this build
     if (npix == 0) return MS_OK;
+    if (R > 4 && D % 4 == 0 && C >= (R + 3) / 4 * 4) {
+        switch ((R + 3) / 4) {
+            case 2: return launch_dt_s<8>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+            case 3: return launch_dt_s<12>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+            case 4: return launch_dt_s<16>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+            case 5: return launch_dt_s<20>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+            case 6: return launch_dt_s<24>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+            case 7: return launch_dt_s<28>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+            default: return launch_dt_s<32>(bwd, a, proj, W, o1, o2, scratch, scratch_floats, npix, D, R, C, s);
+        }
+    }
     switch (dt_rp(R)) {
         case 4: return launch_dt<4>(bwd, a, proj, W, o1, o2, npix, D, R, C, s);
         case 8: return launch_dt<8>(bwd, a, proj, W, o1, o2, npix, D, R, C, s);
@@ -219,13 +462,20 @@ static int dt_dispatch(bool bwd, const float *a, const float *proj, const float 
 
 int dtproj_fwd_dispatch(const float *proj, const float *W, float *delta, int64_t npix, int D, int R, int C, hipStream_t s) {
     if (!proj || !W || !delta) return MS_ERR_NULL;
-    return dt_dispatch(false, nullptr, proj, W, delta, nullptr, npix, D, R, C, s);
+    return dt_dispatch(false, nullptr, proj, W, delta, nullptr, nullptr, 0, npix, D, R, C, s);
 }
 
-int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, int64_t npix, int D,
-                        int R, int C, hipStream_t s) {
+int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, float *scratch,
+                        int64_t scratch_floats, int64_t npix, int D, int R, int C, hipStream_t s) {
     if (!ddelta || !proj || !W || !dproj || !dW) return MS_ERR_NULL;
-    return dt_dispatch(true, ddelta, proj, W, dproj, dW, npix, D, R, C, s);
+    return dt_dispatch(true, ddelta, proj, W, dproj, dW, scratch, scratch_floats, npix, D, R, C, s);
+}
+
+// floats of workspace with which ms_dtproj_bwd sums its per-workgroup dWdt partials without atomics (0: none needed)
+int64_t dtproj_bwd_scratch_floats(int64_t npix, int D, int R) {
+    if (npix <= 0 || D <= 0 || R <= 4 || R > 32 || D % 4 != 0) return 0;
+    const int vpt = (D % 128 == 0) ? 2 : 1;
+    return dw_workers(npix, (D + 256 * vpt - 1) / (256 * vpt)) * 4 * D * R;
 }
 
 }  // namespace ms

@@ -93,10 +93,9 @@ def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R, a
     P.x = x_state.data_ptr()
 
 
-# dt_rank up to which ms_dtproj_* replace the batched GEMMs.  Measured (tools/bench_dtproj.py, MedMamba-T bs 64, fwd+bwd us):
-# R=3: 284 vs 438 (kernels win: K is too small for a GEMM); R=6: 201 vs 142; R=12: 207 vs 113; R=24: 312 vs 75 (few
-# pixels, wide K: a real GEMM).  The kernels tile R <= 32; the product path uses them where they win.
-_DT_KERNEL_MAX_RANK = 4
+# dt_rank up to which ms_dtproj_* are used (above it: batched GEMMs).  R <= 4: the register-tiled kernels (stage 0 of MedMamba-T,
+# 284 vs 438 us fwd+bwd for the GEMMs); R = 5..32: the scalar-operand kernels (csrc/dtproj.hip), measured in tools/bench_dtproj.py.
+_DT_KERNEL_MAX_RANK = int(os.environ.get("MEDSCAN_DT_KERNEL_MAX_RANK", "32"))
 
 
 def _split_k(M):
@@ -126,7 +125,10 @@ def _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C):
     M = B * L
     if R <= _DT_KERNEL_MAX_RANK:
         dwdt = arena.zeros_like(wdt)
+        ns = _lib.lib().ms_dtproj_bwd_scratch_floats(M, D, R)
+        scratch = torch.empty(ns, device=proj.device, dtype=torch.float32) if ns > 0 else None
         _lib.check(_lib.lib().ms_dtproj_bwd(ddelta.data_ptr(), proj.data_ptr(), wdt.data_ptr(), dproj.data_ptr(), dwdt.data_ptr(),
+                                            scratch.data_ptr() if scratch is not None else None, ns,
                                             M, D, R, C, _lib.current_stream_ptr(proj.device)), "ms_dtproj_bwd")
         return dwdt
     dd = ddelta.view(4, M, D)

@@ -445,7 +445,10 @@ def test_fused_block_matches_unfused_block(monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [(200, 96, 3, 35), (64, 192, 6, 38), (50, 384, 12, 44), (49, 768, 24, 56), (33, 70, 5, 37),
-                                 (17, 1024, 32, 64), (9, 130, 1, 33), (64 * 56 * 56, 96, 3, 35)])
+                                 (17, 1024, 32, 64), (9, 130, 1, 33), (64 * 56 * 56, 96, 3, 35),
+                                 # the scalar-operand kernels of ranks 5..32 at the stage shapes of MedMamba-T bs 64 and ragged ones
+                                 (50176, 192, 6, 38), (12544, 384, 12, 44), (3136, 768, 24, 56), (100, 256, 8, 40), (77, 132, 7, 39),
+                                 (1, 64, 9, 41), (300, 128, 32, 64)])
 def test_dtproj_kernels_vs_einsum(cfg):
     """ms_dtproj_fwd/bwd (delta = dts @ Wdt^T read / written in place in the projection rows) vs float64 einsum."""
     from medical_image_classification_amd import _lib
@@ -466,10 +469,19 @@ def test_dtproj_kernels_vs_einsum(cfg):
     dproj = torch.zeros(npix, 4, C, device=dev())
     dproj[:, :, R:] = 7.0                                       # the B|C columns belong to the scan kernel: must stay untouched
     dWd = torch.zeros(4, D, R, device=dev())
-    _lib.check(h.ms_dtproj_bwd(ddd.data_ptr(), pj.data_ptr(), Wd.data_ptr(), dproj.data_ptr(), dWd.data_ptr(), npix, D, R, C, st), "bwd")
+    ns = h.ms_dtproj_bwd_scratch_floats(npix, D, R)
+    scratch = torch.full((max(ns, 1),), float("nan"), device=dev())         # need not be initialised
+    _lib.check(h.ms_dtproj_bwd(ddd.data_ptr(), pj.data_ptr(), Wd.data_ptr(), dproj.data_ptr(), dWd.data_ptr(), scratch.data_ptr(), ns,
+                               npix, D, R, C, st), "bwd")
     assert torch.equal(dproj[:, :, R:], torch.full_like(dproj[:, :, R:], 7.0))
     assert_close(dproj[:, :, :R], ddts.float().numpy(), 1e-4, 1e-5 * float(ddts.abs().max()), "ddts")
     assert_close(dWd, dW.float().numpy(), 1e-4, 2e-5 * float(dW.abs().max()), "dW")
+    # without a workspace: atomics into dWdt, same result
+    dproj2 = torch.zeros(npix, 4, C, device=dev()); dWd2 = torch.zeros(4, D, R, device=dev())
+    _lib.check(h.ms_dtproj_bwd(ddd.data_ptr(), pj.data_ptr(), Wd.data_ptr(), dproj2.data_ptr(), dWd2.data_ptr(), None, 0,
+                               npix, D, R, C, st), "bwd")
+    assert_close(dWd2, dW.float().numpy(), 1e-4, 2e-5 * float(dW.abs().max()), "dW (atomics)")
+    assert_close(dproj2[:, :, :R], ddts.float().numpy(), 1e-4, 1e-5 * float(ddts.abs().max()), "ddts")
 
 
 @pytest.mark.parametrize("case", ["permuted_fp32", "permuted_bf16", "contiguous_bf16"])

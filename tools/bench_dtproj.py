@@ -17,7 +17,8 @@ for D, Hh, R in [(96, 56, 3), (192, 28, 6), (384, 14, 12), (768, 7, 24)]:
     proj = torch.randn(npix, 4, C, device=dev); W = torch.randn(4, D, R, device=dev); dd = torch.randn(4, npix, D, device=dev)
     delta = torch.empty(4, npix, D, device=dev); dproj = torch.zeros_like(proj); dW = torch.zeros_like(W)
     tf = timeit(lambda: h.ms_dtproj_fwd(proj.data_ptr(), W.data_ptr(), delta.data_ptr(), npix, D, R, C, st()))
-    tb = timeit(lambda: h.ms_dtproj_bwd(dd.data_ptr(), proj.data_ptr(), W.data_ptr(), dproj.data_ptr(), dW.data_ptr(), npix, D, R, C, st()))
+    ns = h.ms_dtproj_bwd_scratch_floats(npix, D, R); scr = torch.empty(max(ns, 1), device=dev)
+    tb = timeit(lambda: h.ms_dtproj_bwd(dd.data_ptr(), proj.data_ptr(), W.data_ptr(), dproj.data_ptr(), dW.data_ptr(), scr.data_ptr(), ns, npix, D, R, C, st()))
     dts = proj[:, :, :R].permute(1, 0, 2).contiguous()
     S = next((c for c in (64, 32, 16, 8, 4, 2) if npix % c == 0 and npix // c >= 1024), 1)
     rf = timeit(lambda: torch.bmm(dts, W.transpose(1, 2)))
