@@ -94,6 +94,18 @@ typedef enum MsStatus {
                                 ms_dtproj_bwd); MsScanBwdParams.ddt_x / ddt_w are reserved for that backward (same addressing
                                 as dB / (dim, dt_rank), accumulated) and are ignored today. */
 
+#define MS_SCAN_LATTICE 256   /* SS2D mode only: the four groups scan the four (row parity, column parity) sub-lattices of the
+                                map_h x map_w map (both even) instead of the four full-resolution directions -- FusionMamba's
+                                stride-2 `EfficientScan` / `EfficientMerge` (CrossMamba/FusionMamba/models/cross.py:139-190,
+                                34-88) as an addressing mode of the scan kernels: seqlen = (map_h/2) * (map_w/2), and step l of
+                                group k visits  k = 0: (row 2i,   col 2j)    row-major (i = l / (map_w/2), j = l % (map_w/2))
+                                                k = 1: (row 2b+1, col 2a)    column-major (a = l / (map_h/2), b = l % (map_h/2))
+                                                k = 2: (row 2i,   col 2j+1)  row-major
+                                                k = 3: (row 2b+1, col 2a+1)  column-major.
+                                Every pixel belongs to exactly one group, so one pixel-order tensor (group stride 0) can hold
+                                all four groups' out / du / ddelta: the merge is free.  Odd sizes: the caller zero-pads the map to
+                                even sizes (what cross.py:148-156 does to the sequences). */
+
 typedef struct MsScanParams {
     int32_t batch, dim, seqlen, dstate, n_groups;
     int32_t delta_softplus;                 /* flags: MS_SCAN_SOFTPLUS | MS_SCAN_A_IS_LOG (historically a bool: 1 = softplus) */

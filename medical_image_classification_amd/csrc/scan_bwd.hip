@@ -137,10 +137,10 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     float *dub = q.du + b * q.du_batch_stride + g * q.du_group_stride + c0w * q.du_d_stride;
     float *ddb = q.ddelta + b * q.ddelta_batch_stride + g * q.ddelta_group_stride + c0w * q.ddelta_d_stride;
     PosMap pm;
-    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.L = L;
-    pm.H = __builtin_amdgcn_readfirstlane(p.map_h); pm.W = __builtin_amdgcn_readfirstlane(p.map_w);
-    pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
-    pm.tab = nullptr; pm.tab_base = 0;
+    pm.mode = -1; pm.L = L; pm.H = 0; pm.W = 0; pm.invH = 0.0f; pm.tab = nullptr; pm.tab_base = 0;
+    if (MODE == kModeSS2D)
+        pm.setup(g, __builtin_amdgcn_readfirstlane(p.map_h), __builtin_amdgcn_readfirstlane(p.map_w), L,
+                 (p.delta_softplus & MS_SCAN_LATTICE) != 0);
     PosMap pmb = pm;                         // B/C rows (and dB/dC): same order as the activations unless BCM
     if (BCM) pmb.mode = ((p.delta_softplus >> 4) & 7) - 1;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
@@ -421,6 +421,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 }
 
 int validate_scan(const MsScanParams &p);
+int scan_positions(const MsScanParams &p);
 int pick_npl(int dstate, int sg);
 bool use_cw8(const MsScanParams &p, bool backward);
 int pick_mode(bool l_contig, bool d_contig, bool small, int map_h);
@@ -464,9 +465,10 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
     if (rc != MS_OK) return rc;
     if (!q.dout || !q.du || !q.ddelta || !q.dA || !q.dB || !q.dC) return MS_ERR_NULL;
     if (p.delta_softplus & MS_SCAN_DT_FUSED) return MS_ERR_UNSUPPORTED;     // forward-only this build
-    if (!act_strides_ok(q.dout_d_stride, q.dout_l_stride, p.seqlen) || !act_strides_ok(q.du_d_stride, q.du_l_stride, p.seqlen) ||
-        !act_strides_ok(q.ddelta_d_stride, q.ddelta_l_stride, p.seqlen) ||
-        !act_strides_ok(q.dB_dstate_stride * 4, q.dB_l_stride, p.seqlen) || !act_strides_ok(q.dC_dstate_stride * 4, q.dC_l_stride, p.seqlen))
+    const int npos = scan_positions(p);
+    if (!act_strides_ok(q.dout_d_stride, q.dout_l_stride, npos) || !act_strides_ok(q.du_d_stride, q.du_l_stride, npos) ||
+        !act_strides_ok(q.ddelta_d_stride, q.ddelta_l_stride, npos) ||
+        !act_strides_ok(q.dB_dstate_stride * 4, q.dB_l_stride, npos) || !act_strides_ok(q.dC_dstate_stride * 4, q.dC_l_stride, npos))
         return MS_ERR_STRIDE;
     if (p.map_h > 0 && (q.dout_d_stride != 1 || q.du_d_stride != 1 || q.ddelta_d_stride != 1 ||
                         q.dB_dstate_stride != 1 || q.dC_dstate_stride != 1)) return MS_ERR_STRIDE;

@@ -75,17 +75,36 @@ __device__ __forceinline__ void wave_sync() {
 // Sequence index -> memory position.  mode < 0: identity (plain sequences).  mode 0..3: the pixel visited at
 // step l by direction `mode` of SS2D's cross-scan over an H x W map (MedMamba.py:393-395):
 //   0: l    1: (l % H)*W + l / H    2: L-1-l    3: map1(L-1-l)
+// mode 4..7 (MS_SCAN_LATTICE): sub-lattice k = mode - 4 of FusionMamba's stride-2 scan (cross.py:139-190), see medscan.h; then
+// H holds the INNER count of the sequence order (map_w/2 for the row-major lattices 0, 2; map_h/2 for the column-major 1, 3),
+// invH its reciprocal and W the full map width.
 struct PosMap {
     int mode, H, W, L;
     float invH;
     const int *tab;        // SS2D mode: LDS table of the current chunk's kCL positions (filled by fill_table)
     int tab_base;          // first sequence index the table covers
+    // SS2D-mode setup of group g: the four cross-scan directions, or the four stride-2 sub-lattices
+    __device__ __forceinline__ void setup(int g, int map_h, int map_w, int L_, bool lattice) {
+        L = L_; tab = nullptr; tab_base = 0;
+        if (!lattice) { mode = g & 3; H = map_h; W = map_w; invH = 1.0f / (float)map_h; return; }
+        mode = 4 + (g & 3);
+        H = (g & 1) ? map_h / 2 : map_w / 2;
+        W = map_w; invH = 1.0f / (float)H;
+    }
     __device__ __forceinline__ void fill_table(int *t, int lbase, int lane) {
         if (lane < kCL) t[lane] = (*this)(min(lbase + lane, L - 1));
         tab = t; tab_base = lbase;
     }
     __device__ __forceinline__ int operator()(int l) const {
         if (mode < 0) return l;
+        if (mode >= 4) {
+            const int q = (int)(((float)l + 0.5f) * invH);      // l / inner, exact for l < 2^22
+            const int r = l - __mul24(q, H);
+            const int odd = mode & 1, hi = (mode >> 1) & 1;
+            const int row = odd ? 2 * r + 1 : 2 * q;
+            const int col = (odd ? 2 * q : 2 * r) + hi;
+            return __mul24(row, W) + col;
+        }
         int t = (mode & 2) ? L - 1 - l : l;
         if (mode & 1) {
             const int w = (int)(((float)t + 0.5f) * invH);      // exact for t < 2^22

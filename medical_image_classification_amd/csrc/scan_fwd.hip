@@ -101,10 +101,10 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
     const float *db = p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0w * p.delta_d_stride;
     float *ob = p.out + b * p.out_batch_stride + g * p.out_group_stride + c0w * p.out_d_stride;
     PosMap pm;
-    pm.mode = MODE == kModeSS2D ? (g & 3) : -1; pm.L = L;
-    pm.H = __builtin_amdgcn_readfirstlane(p.map_h); pm.W = __builtin_amdgcn_readfirstlane(p.map_w);
-    pm.invH = MODE == kModeSS2D ? 1.0f / (float)p.map_h : 0.0f;
-    pm.tab = nullptr; pm.tab_base = 0;
+    pm.mode = -1; pm.L = L; pm.H = 0; pm.W = 0; pm.invH = 0.0f; pm.tab = nullptr; pm.tab_base = 0;
+    if (MODE == kModeSS2D)
+        pm.setup(g, __builtin_amdgcn_readfirstlane(p.map_h), __builtin_amdgcn_readfirstlane(p.map_w), L,
+                 (p.delta_softplus & MS_SCAN_LATTICE) != 0);
     PosMap pmb = pm;                         // B/C rows: same order as the activations unless BCM
     if (BCM == 1) pmb.mode = ((p.delta_softplus >> 4) & 7) - 1;
     const int nd = BCM == 2 ? N / 4 : N;                    // states per direction slice
@@ -279,6 +279,10 @@ bool act_strides_ok(int64_t sd, int64_t sl, int seqlen) {
     return fits_u32((sd * 16 + sl * (int64_t)(seqlen > 0 ? seqlen : 1)) * 4);
 }
 
+// positions a tensor of the problem is indexed with: the sequence length, or every pixel of the map in SS2D mode (the stride-2
+// sub-lattices visit a quarter of them each)
+int scan_positions(const MsScanParams &p) { return p.map_h > 0 ? p.map_h * p.map_w : p.seqlen; }
+
 int validate_scan(const MsScanParams &p) {
     const bool dtf = (p.delta_softplus & MS_SCAN_DT_FUSED) != 0;
     if (!p.u || (!p.delta && !dtf) || !p.A || !p.B || !p.C) return MS_ERR_NULL;
@@ -287,13 +291,17 @@ int validate_scan(const MsScanParams &p) {
     if (p.dim % p.n_groups != 0) return MS_ERR_SHAPE;
     if (p.dstate > 256) return MS_ERR_DSTATE;
     if (p.map_h < 0 || p.map_w < 0 || (p.map_h > 0) != (p.map_w > 0)) return MS_ERR_SHAPE;
+    const bool lattice = (p.delta_softplus & MS_SCAN_LATTICE) != 0;
+    if (lattice && (p.map_h <= 0 || p.map_h % 2 != 0 || p.map_w % 2 != 0 || ((p.delta_softplus >> 4) & 7) != 0 || dtf)) return MS_ERR_SHAPE;
     if (p.map_h > 0) {
-        if ((int64_t)p.map_h * p.map_w != p.seqlen || p.n_groups % 4 != 0 || p.seqlen >= (1 << 22)) return MS_ERR_SHAPE;
+        const int64_t want = lattice ? (int64_t)(p.map_h / 2) * (p.map_w / 2) : (int64_t)p.map_h * p.map_w;
+        if (want != p.seqlen || p.n_groups % 4 != 0 || (int64_t)p.map_h * p.map_w >= (1 << 22)) return MS_ERR_SHAPE;
         // SS2D mode needs channel-last activations and projection rows that are contiguous along the state axis
         if (p.u_d_stride != 1 || (!dtf && p.delta_d_stride != 1) || p.B_dstate_stride != 1 || p.C_dstate_stride != 1) return MS_ERR_STRIDE;
     }
-    if (!act_strides_ok(p.u_d_stride, p.u_l_stride, p.seqlen) || (!dtf && !act_strides_ok(p.delta_d_stride, p.delta_l_stride, p.seqlen)) ||
-        !act_strides_ok(p.B_dstate_stride * 4, p.B_l_stride, p.seqlen) || !act_strides_ok(p.C_dstate_stride * 4, p.C_l_stride, p.seqlen))
+    const int npos = scan_positions(p);
+    if (!act_strides_ok(p.u_d_stride, p.u_l_stride, npos) || (!dtf && !act_strides_ok(p.delta_d_stride, p.delta_l_stride, npos)) ||
+        !act_strides_ok(p.B_dstate_stride * 4, p.B_l_stride, npos) || !act_strides_ok(p.C_dstate_stride * 4, p.C_l_stride, npos))
         return MS_ERR_STRIDE;
     return MS_OK;
 }
@@ -305,7 +313,7 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
     int rc = validate_scan(p);
     if (rc != MS_OK) return rc;
     if (!p.out) return MS_ERR_NULL;
-    if (!act_strides_ok(p.out_d_stride, p.out_l_stride, p.seqlen)) return MS_ERR_STRIDE;
+    if (!act_strides_ok(p.out_d_stride, p.out_l_stride, scan_positions(p))) return MS_ERR_STRIDE;
     if (p.map_h > 0 && p.out_d_stride != 1) return MS_ERR_STRIDE;
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;

@@ -284,6 +284,7 @@ bool fits24(int64_t v);
 bool ss2d_fast_ok(const MsScanParams &p) {
     if (p.map_h <= 0 || p.dstate != kN || p.A_dstate_stride == 0) return false;
     if (((p.delta_softplus >> 4) & 7) != 0) return false;                         // MS_SCAN_BC_MAP: SSD forms
+    if (p.delta_softplus & MS_SCAN_LATTICE) return false;                         // stride-2 sub-lattices: general kernels
     const int dpg = p.dim / p.n_groups;
     if (dpg % 4 != 0) return false;
     const bool dtf = (p.delta_softplus & MS_SCAN_DT_FUSED) != 0;

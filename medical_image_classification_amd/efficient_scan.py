@@ -11,16 +11,25 @@ The image is split into its four (row parity, column parity) sub-lattices, zero-
 sequence of a quarter of the pixels:
     k = 0: rows 2i,   cols 2j,   row-major          k = 1: rows 2i+1, cols 2j,   column-major
     k = 2: rows 2i,   cols 2j+1, row-major          k = 3: rows 2i+1, cols 2j+1, column-major
-Both directions of the mapping are ONE gather each here (every pixel belongs to exactly one (k, l); padded positions read
-as zero): bit-exact, no strided slice assignments.  The scan itself is this package's selective_scan_fn (HIP kernels; the
-`nrows` argument is a tiling detail of the reference's CUDA kernel and is ignored).  The step-2 addressing inside the scan
-kernel (as the SS2D mode does for the full-resolution directions) is the next step for this row.
+`EfficientScan` / `EfficientMerge` themselves: both directions of the mapping are ONE gather each (every pixel belongs to exactly
+one (k, l); padded positions read as zero): bit-exact, no strided slice assignments.
+
+`cross_selective_scan*` (what the modules call) never materialise the sequences on CUDA: the scan kernels take the four
+sub-lattices as an ADDRESSING MODE (`MS_SCAN_LATTICE`, include/medscan.h; `PosMap` modes 4-7 in csrc/scan_common.h) -- the
+activations are read in place from the channel-last image, x_proj / dt_proj run per pixel (no gathers in front of them), and
+every pixel of the result is written by exactly one group, so the merge costs nothing.  Maps with an odd size are zero-padded to
+even sizes first (the reference pads the sequences, cross.py:148-156: the same zeros).  `nrows` is a tiling detail of the
+reference's CUDA kernel and is ignored.  MEDSCAN_LATTICE_KERNEL=0 (or CPU tensors / d_state > 16) takes the gather formulation.
 """
 import math
+import os
 
 import torch
+import torch.nn.functional as F
 
 from .selective_scan_interface import selective_scan_fn
+
+_LATTICE_KERNEL = os.environ.get("MEDSCAN_LATTICE_KERNEL", "1") == "1"
 
 _IDX_CACHE = {}
 
@@ -98,6 +107,24 @@ def _core(x, x_proj_weight, x_proj_bias, dt_projs_weight, dt_projs_bias, A_logs,
     B, _, H, W = x.shape
     N = A_logs.shape[1]
     K, D, R = dt_projs_weight.shape
+    if (_LATTICE_KERNEL and x.is_cuda and step_size == 2 and K == 4 and N <= 16 and R <= 32 and delta_softplus
+            and H * W < (1 << 20)):
+        # the sub-lattices as an addressing mode of the scan kernels: pixel-order operands, no gathers (see the module docstring)
+        from .ss2d_fused import _SS2DScan
+        with torch.autocast(device_type="cuda", enabled=False):
+            Hp, Wp = H + (H & 1), W + (W & 1)
+            xc = x.float().permute(0, 2, 3, 1)                                                # (B,H,W,D)
+            if (Hp, Wp) != (H, W):
+                xc = F.pad(xc, (0, 0, 0, Wp - W, 0, Hp - H))
+            xc = xc.contiguous()
+            C = R + 2 * N
+            proj = F.linear(xc.view(B * Hp * Wp, D), x_proj_weight.float().reshape(4 * C, D),
+                            x_proj_bias.float().reshape(4 * C) if x_proj_bias is not None else None).view(B, Hp * Wp, 4, C)
+            y = _SS2DScan.apply(xc, proj, None, dt_projs_weight.float(), -torch.exp(A_logs.float()), Ds.float().view(-1),
+                                dt_projs_bias.float().view(-1), Hp, Wp, N, R, True)            # (B, Hp*Wp, D), merged
+            y = y.view(B, Hp, Wp, D)[:, :H, :W, :]
+            y = out_norm(y.reshape(B, H * W, D)).view(B, H, W, -1)
+        return y.to(x.dtype) if to_dtype else y
     xs = EfficientScan.apply(x, step_size)                                                   # (B,4,D,L2)
     L = xs.shape[-1]
     x_dbl = torch.einsum("b k d l, k c d -> b k c l", xs, x_proj_weight)

@@ -141,8 +141,11 @@ def _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C):
 
 class _SS2DScan(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xc, proj, delta, wdt, A, Ds, dt_bias, H, W, N, R):
-        """xc (B,H,W,D), proj (B,L,4,R+2N), A (4D,N), Ds (4D), dt_bias (4D): fp32 contiguous; either delta (4,B,L,D) or
+    def forward(ctx, xc, proj, delta, wdt, A, Ds, dt_bias, H, W, N, R, lattice=False):
+        """lattice=True: the four groups scan the four stride-2 sub-lattices of the (even-sized) map instead of the four
+        full-resolution directions (MS_SCAN_LATTICE: FusionMamba's EfficientScan / EfficientMerge, cross.py:139-190,34-88, as an
+        addressing mode): sequences of H*W/4 pixels, every pixel written by exactly one group -> y IS the merged result.
+        xc (B,H,W,D), proj (B,L,4,R+2N), A (4D,N), Ds (4D), dt_bias (4D): fp32 contiguous; either delta (4,B,L,D) or
         wdt (4,D,R) (then delta = dts @ wdt^T is computed here, ms_dtproj_fwd).
         Returns y (B,L,D) = ((y0 + y2) + y1) + y3 with every y_k in pixel order (add order of MedMamba.py:476)."""
         _lib.require_cuda(xc, proj, A, Ds, dt_bias)
@@ -157,34 +160,45 @@ class _SS2DScan(torch.autograd.Function):
                 delta = _dtproj_fwd(proj, wdt, B, L, D, R, R + 2 * N)
             else:
                 delta = delta.contiguous()
-        y4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
-        x_state = torch.empty((B, lib.ms_scan_n_chunks(L), N, 4 * D), device=xc.device, dtype=torch.float32)
+        if lattice and (H % 2 or W % 2):
+            raise RuntimeError("ss2d scan, lattice mode: the map must have even sizes (zero-pad it, cross.py:148-156)")
+        Lq = L // 4 if lattice else L                    # sequence length of one group
+        y4 = torch.empty((B, L, D) if lattice else (4, B, L, D), device=xc.device, dtype=torch.float32)
+        x_state = torch.empty((B, lib.ms_scan_n_chunks(Lq), N, 4 * D), device=xc.device, dtype=torch.float32)
         P = MsScanParams()
         _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, y4, x_state, H, W, N, R)
+        if lattice:
+            P.seqlen, P.out_group_stride = Lq, 0
+            P.delta_softplus |= 256                       # MS_SCAN_LATTICE
         with _lib.on_device(xc.device):
-            rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), xc.device,
+            rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, Lq, N, 4, False), xc.device,
                               lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(xc.device)))
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
         ctx.save_for_backward(xc, proj, delta, A, Ds, dt_bias, x_state, wdt if ctx.has_wdt else None)
-        ctx.geom = (H, W, N, R)
-        return (y4[0] + y4[2]) + y4[1] + y4[3]
+        ctx.geom = (H, W, N, R, bool(lattice))
+        return y4 if lattice else (y4[0] + y4[2]) + y4[1] + y4[3]
 
     @staticmethod
     def backward(ctx, dy):
         xc, proj, delta, A, Ds, dt_bias, x_state, wdt = ctx.saved_tensors
-        H, W, N, R = ctx.geom
+        H, W, N, R, lattice = ctx.geom
         lib = _lib.lib()
         B, D, L = xc.shape[0], xc.shape[-1], H * W
         C = R + 2 * N
         dy = dy.contiguous().float()                              # (B,L,D): dout of all four directions (group stride 0)
-        du4 = torch.empty((4, B, L, D), device=xc.device, dtype=torch.float32)
-        ddelta = torch.empty_like(du4)
+        # lattice: every pixel belongs to one group -> ONE du tensor (group stride 0); ddelta keeps its four slabs (the
+        # projection backward sums over all of them), of which a group writes only its own pixels: zero-filled first
+        du4 = torch.empty((B, L, D) if lattice else (4, B, L, D), device=xc.device, dtype=torch.float32)
+        ddelta = torch.zeros((4, B, L, D), device=xc.device, dtype=torch.float32) if lattice else torch.empty_like(du4)
         dproj = arena.zeros_like(proj)
         dA, dD, dbias = arena.zeros_like(A), arena.zeros_like(Ds), arena.zeros_like(dt_bias)
         Q = MsScanBwdParams()
         _ss2d_params(Q.f, xc, proj, delta, A, Ds, dt_bias, None, x_state, H, W, N, R)
+        if lattice:
+            Q.f.seqlen = L // 4
+            Q.f.delta_softplus |= 256                     # MS_SCAN_LATTICE
         Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
-        Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, B * L * D, 1, D
+        Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, (0 if lattice else B * L * D), 1, D
         Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * D, B * L * D, 1, D
         Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = L * 4 * C, C, 1, 4 * C
         Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = L * 4 * C, C, 1, 4 * C
@@ -196,8 +210,8 @@ class _SS2DScan(torch.autograd.Function):
                               lambda: lib.ms_selective_scan_bwd(ctypes.byref(Q), _lib.current_stream_ptr(xc.device)))
             _lib.check(rc, "ms_selective_scan_bwd[ss2d]")
             dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C) if ctx.has_wdt else None
-        dxc = du4.sum(dim=0).view_as(xc)
-        return dxc, dproj, (None if ctx.has_wdt else ddelta), dwdt, dA, dD, dbias, None, None, None, None
+        dxc = du4.view_as(xc) if lattice else du4.sum(dim=0).view_as(xc)
+        return dxc, dproj, (None if ctx.has_wdt else ddelta), dwdt, dA, dD, dbias, None, None, None, None, None
 
 
 def _pixel_view(t, D):

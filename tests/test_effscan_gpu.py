@@ -56,3 +56,31 @@ def test_selective_scan_namespace_and_gpu_permutations():
     assert torch.equal(xs.cpu(), es.EfficientScan.apply(x.cpu(), 2))
     with pytest.raises(AssertionError):
         es.SelectiveScan.apply(x, x, x, x, x, None, None, True, 8)
+
+
+@pytest.mark.parametrize("cfg", [(2, 96, 28, 28, 16, 6), (1, 48, 9, 14, 16, 3), (2, 32, 64, 64, 8, 2)])
+def test_lattice_addressing_mode_matches_gather_formulation(cfg, monkeypatch):
+    """The stride-2 sub-lattices as an addressing mode of the scan kernels (MS_SCAN_LATTICE: no sequences materialised) against
+    the gather formulation of the same functions (EfficientScan -> selective_scan_fn -> EfficientMerge, itself pinned by the
+    reference-run vectors above) at FusionMamba-sized maps: output and every gradient."""
+    from medical_image_classification_amd import efficient_scan as es
+    B, D, H, W, N, R = cfg
+    gen = torch.Generator().manual_seed(11)
+    C = R + 2 * N
+    mk = lambda *s, scale=1.0: (torch.randn(*s, generator=gen) * scale).to(dev())
+    base = dict(x=mk(B, D, H, W), xw=mk(4, C, D, scale=D ** -0.5), dw=mk(4, D, R, scale=R ** -0.5), db=mk(4, D, scale=0.5) - 3.0,
+                al=torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(4 * D, 1).to(dev()), ds=torch.ones(4 * D, device=dev()))
+    gy = mk(B, H, W, D)
+    res = []
+    for native in (True, False):
+        monkeypatch.setattr(es, "_LATTICE_KERNEL", native)
+        t = {k: v.clone().requires_grad_() for k, v in base.items()}
+        norm = torch.nn.LayerNorm(D).to(dev())
+        y = es.cross_selective_scan(t["x"], t["xw"], None, t["dw"], t["db"], t["al"], t["ds"], out_norm=norm, nrows=1)
+        y.backward(gy)
+        res.append((y.detach(), {k: v.grad for k, v in t.items()}, norm.weight.grad))
+    (y1, g1, n1), (y0, g0, n0) = res
+    close(y1, y0.cpu().numpy(), 1e-4, "y")
+    for k in base:
+        close(g1[k], g0[k].cpu().numpy(), 2e-3, f"d{k}")
+    close(n1, n0.cpu().numpy(), 2e-3, "dnorm_w")
