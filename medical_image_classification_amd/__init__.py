@@ -5,6 +5,7 @@ Public surface (same names as the reference):
   selective_scan_fn, SelectiveScanFn                       (mamba_ssm/ops/selective_scan_interface.py)
   SS2D, SS_Conv_SSM, VSSLayer, VSSM, PatchEmbed2D, PatchMerging2D, channel_shuffle   (MedMamba.py)
   aliases: VSSBlock = SS_Conv_SSM, MedMamba = VSSM
+  medical_image_classification_amd.cross: SS2D, SS2D_cross_new, VSSBlock_new, VSSBlock_Cross_new, ...  (FusionMamba cross.py)
 """
 from .selective_scan_interface import SelectiveScanFn, selective_scan_fn  # noqa: F401
 
