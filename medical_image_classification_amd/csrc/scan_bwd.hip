@@ -24,8 +24,14 @@ namespace ms {
 
 constexpr int kWPB = 4;      // waves per workgroup in the backward: independent except for the per-chunk dB/dC combine
 
+#ifndef MS_BWD_PK
+#define MS_BWD_PK 1      // packed fp32 state pairs in the sweeps (2 states per lane, SS2D mode): see the kPk blocks
+#endif
 #ifndef MS_BWD_DPP
-#define MS_BWD_DPP 0     // measured: 5.86 vs 5.64 ms per step (the kernel is VALU-issue bound: +13 % VALU costs more than the LDS round trips saved)
+#define MS_BWD_DPP 1     // channel sums of dB / dC in registers (banked DPP adds) instead of an LDS transpose; used WITH the packed
+                         // sweeps only.  Measured (MedMamba-T bs 64, ms per step of the 10 SS2D backward launches, same box):
+                         // scalar + LDS 5.94 | scalar + DPP 6.17 | packed + LDS 6.20 | packed + DPP 5.42.  Either change alone loses
+                         // (more VALU for the DPP sums / the LDS pipe becomes the bound once the VALU work shrinks); together they win.
 #endif
 // Sum over the wave's 8 channel lanes (lane bits 0-2) of the 8 (position, state) values of a batch, scattered: lane c ends up
 // with the total of v[c].  Pure VALU (DPP row_ror / quad_perm adds + selects, 21 instructions): replaces a transpose through a
@@ -34,19 +40,21 @@ constexpr int kWPB = 4;      // waves per workgroup in the backward: independent
 // clear read lane + 4 through row_ror:12; banks 1, 3 read lane - 4 through row_ror:4).  Inline assembly: the builtin only offers
 // the move form.  s_nop 1 = the two wait states a DPP read of a just-written VGPR needs (the compiler's hazard recognizer does
 // not look inside asm blocks).
-__device__ __forceinline__ float xchg_add4_banked(float lo, float hi) {
-    float r;
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
-                 : "=&v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
 __device__ __forceinline__ float chan_scatter8(const float (&v)[8], int lane) {
-    float a[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = xchg_add4_banked(v[q], v[q + 4]);
-    const float b0 = xchg_add<2>(a[0], a[2], lane), b1 = xchg_add<2>(a[1], a[3], lane);
+    float a0, a1, a2, a3;
+    // one block for the four (v[q], v[q+4]) pairs: a single s_nop covers the freshest input, the DPP adds are independent
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+    const float b0 = xchg_add<2>(a0, a2, lane), b1 = xchg_add<2>(a1, a3, lane);
     return xchg_add<1>(b0, b1, lane);
 }
 
@@ -65,8 +73,9 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     using Rows = RowIO<MODE, NP, kWPB>;
     constexpr int kPitch = Tile::kPitch, kTile = Tile::kTile, kCW = CW;
     const MsScanParams &p = q.f;
-    __shared__ __attribute__((aligned(16))) float sB[NP * kRowPitch];          // B / C rows of the chunk: one copy per workgroup
-    __shared__ __attribute__((aligned(16))) float sC[NP * kRowPitch];
+    constexpr int kRowsLds = NP * kRowPitch > kCL * (NP + 4) ? NP * kRowPitch : kCL * (NP + 4);       // either tile layout fits
+    __shared__ __attribute__((aligned(16))) float sB[kRowsLds];                // B / C rows of the chunk: one copy per workgroup
+    __shared__ __attribute__((aligned(16))) float sC[kRowsLds];
     // this chunk's dB | dC of each wave's channels; the dC tile sits 2 banks past a multiple of 64 from the dB tile, so the
     // workgroup combine (which reads dB[n][l] and dC[n][l] in one instruction) finds them in different banks
     constexpr int kDC = NP * kRowPitch + 2;
@@ -86,7 +95,11 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     int (*spos)[kCL] = spos_[wv];
     const int c = lane % CW, sg = lane / CW;
     // register (DPP) channel sums: lane (sg, c) owns value c of its group's 8 = position lb + c / 2, state sg * NPL + c % 2
-    constexpr bool kDppSums = MS_BWD_DPP && CW == 8 && NPL == 2;
+    // packed sweeps: a lane's two states are one v2f; the B / C tiles are laid out [position][state] (pitch kRPk) so that a pair is
+    // one ds_read_b64
+    constexpr bool kPk = MS_BWD_PK && NPL == 2 && CW == 8 && !SA && !BCM && MODE == kModeSS2D;
+    constexpr bool kDppSums = MS_BWD_DPP && kPk;
+    constexpr int kRPk = NP + 4;
     const int t_dpp = (sg * NPL + (c & 1)) * kRowPitch + (c >> 1);
     // transpose-reduce ownership: lane rr sums row rr = (j*NPL + i)*SG + sg' -> position lb + j, state sg'*NPL + i
     const int t_out = ((lane % SG) * NPL + (lane / SG) % NPL) * kRowPitch + lane / (NPL * SG);
@@ -208,8 +221,13 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         tile.put(sg_, rg, nvalid, len);
 #pragma unroll
         for (int k = 0; k < Tile::NE; ++k) dDk[Tile::ak(k)] = fmaf(rg[k], ru[k], dDk[Tile::ak(k)]);       // out-of-range elements are zero
-        rows.put(sB, rB, N, len);
-        rows.put(sC, rC, N, len);
+        if constexpr (kPk) {
+            rows.template put_t<NPL, kRPk>(sB, rB, N, len);
+            rows.template put_t<NPL, kRPk>(sC, rC, N, len);
+        } else {
+            rows.put(sB, rB, N, len);
+            rows.put(sC, rC, N, len);
+        }
         float h[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -219,6 +237,87 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         __syncthreads();                                   // the B/C tiles are staged by all waves of the workgroup
         if (ch > 0) fetch(ch - 1);                         // lands while this chunk is computed
 
+        if constexpr (kPk) {
+            // ================= packed sweeps (same algebra as below, two states per instruction) =================
+            const v2f A2p = {A2[0], A2[1]}, Anp = {An[0], An[1]};
+            v2f hp = {h[0], h[1]}, dhp = {dhc[0], dhc[1]}, dAp = {dAacc[0], dAacc[1]};
+            v2f ap[kCL], ckp[NB];
+            const float *sBl = sB + sg * NPL, *sCl = sC + sg * NPL;          // this lane's state pair inside a position row
+#pragma unroll
+            for (int l = 0; l < kCL; ++l) {
+                if ((l & 3) == 0) ckp[l >> 2] = hp;
+                const float dl_ = sdl[l * kPitch + c];
+                const float du_ = dl_ * su[l * kPitch + c];
+                const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPk);
+                ap[l] = exp2_pk(splat(dl_) * A2p);
+                hp = pk_fma(ap[l], hp, splat(du_) * Bp);
+            }
+#pragma unroll
+            for (int kb = NB - 1; kb >= 0; --kb) {
+                const int lb = kb * 4;
+                v2f Bp[4], Cp[4], bu[4], hv[4];
+                float dl4[4], u4[4], g4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Bp[j] = *reinterpret_cast<const v2f *>(sBl + (lb + j) * kRPk);
+                    Cp[j] = *reinterpret_cast<const v2f *>(sCl + (lb + j) * kRPk);
+                    dl4[j] = sdl[(lb + j) * kPitch + c]; u4[j] = su[(lb + j) * kPitch + c]; g4[j] = sg_[(lb + j) * kPitch + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bu[j] = splat(dl4[j] * u4[j]) * Bp[j];
+                    hv[j] = pk_fma(ap[lb + j], j > 0 ? hv[j > 0 ? j - 1 : 0] : ckp[kb], bu[j]);
+                }
+                float duv[4], ddv[4], vB8[8], vC8[8];
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const float du_ = dl4[j] * u4[j];
+                    const v2f dhn = pk_fma(Cp[j], splat(g4[j]), dhp);
+                    const v2f w = hv[j] - bu[j];                         // = a_j * h_{j-1}
+                    const v2f t1 = dhn * Bp[j];
+                    const v2f qv = dhn * w;
+                    const v2f t2 = qv * Anp;
+                    dAp = pk_fma(qv, splat(dl4[j]), dAp);
+                    const v2f vb = dhn * splat(du_), vc = splat(g4[j]) * hv[j];
+                    vB8[2 * j] = vb.x; vB8[2 * j + 1] = vb.y; vC8[2 * j] = vc.x; vC8[2 * j + 1] = vc.y;
+                    dhp = ap[lb + j] * dhn;
+                    const float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
+                    duv[j] = fmaf(s1, dl4[j], Dv * g4[j]);
+                    ddv[j] = fmaf(s1, u4[j], s2);
+                }
+                const float du_t = sum_groups_scatter4<CW>(duv, lane);
+                const float dd_t = sum_groups_scatter4<CW>(ddv, lane);
+                if (is_group_owner<CW>(lane)) {
+                    const int lo = lb + group_slot<CW>(lane);
+                    su[lo * kPitch + c] = du_t;
+                    sg_[lo * kPitch + c] = dd_t;
+                }
+                if constexpr (kDppSums) {
+                    sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
+                    sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
+                } else {
+                    wave_sync();
+#pragma unroll
+                    for (int r = 0; r < 4 * NPL; ++r) {
+                        sTB[(r * SG + sg) * kTP + c] = vB8[r];
+                        sTC[(r * SG + sg) * kTP + c] = vC8[r];
+                    }
+                    wave_sync();
+                    float tb = 0.0f, tc = 0.0f;
+#pragma unroll
+                    for (int k4 = 0; k4 < kQ; ++k4) {
+                        const int q4 = 4 * ((k4 + lane / (16 / kQ)) % kQ);
+                        const float4 x = *reinterpret_cast<const float4 *>(sTB + lane * kTP + q4);
+                        const float4 y = *reinterpret_cast<const float4 *>(sTC + lane * kTP + q4);
+                        tb += (x.x + x.y) + (x.z + x.w);
+                        tc += (y.x + y.y) + (y.z + y.w);
+                    }
+                    sdB[t_out + lb] = tb;
+                    sdC[t_out + lb] = tc;
+                }
+            }
+            dhc[0] = dhp.x; dhc[1] = dhp.y; dAacc[0] = dAp.x; dAacc[1] = dAp.y;
+        } else {
         // ---- forward sweep: the decay a of EVERY position stays in registers (each exp2 is evaluated once per
         //      backward), h only at the start of every 4-position batch ------------------------------------
         constexpr int NA = SA ? 1 : NPL;                       // decays stored per position
@@ -340,6 +439,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 sdC[t_out + lb] = tc;
             }
         }
+        }   // !kPk
         wave_sync();
         if (MODE == kModeSS2D) {                                                 // the prefetch moved the maps to the next chunk
             pm.tab = spos[ch & 1]; pm.tab_base = l0;
