@@ -97,8 +97,9 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     // register (DPP) channel sums: lane (sg, c) owns value c of its group's 8 = position lb + c / 2, state sg * NPL + c % 2
     // packed sweeps: a lane's two states are one v2f; the B / C tiles are laid out [position][state] (pitch kRPk) so that a pair is
     // one ds_read_b64
-    constexpr bool kPk = MS_BWD_PK && NPL == 2 && CW == 8 && !SA && !BCM && MODE == kModeSS2D;
-    constexpr bool kDppSums = MS_BWD_DPP && kPk;
+    // (packed sweeps and register channel sums go together: either alone loses, see MS_BWD_DPP)
+    constexpr bool kPk = MS_BWD_PK && MS_BWD_DPP && NPL == 2 && CW == 8 && !SA && !BCM && MODE == kModeSS2D;
+    constexpr bool kDppSums = kPk;
     constexpr int kRPk = NP + 4;
     const int t_dpp = (sg * NPL + (c & 1)) * kRowPitch + (c >> 1);
     // transpose-reduce ownership: lane rr sums row rr = (j*NPL + i)*SG + sg' -> position lb + j, state sg'*NPL + i
@@ -216,9 +217,25 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         float *sdB = sdBC_[ch & 1][wv], *sdC = sdBC_[ch & 1][wv] + kDC;
-        tile.put(su, ru, nvalid, len);
+        // packed path: the per-(position, channel) scalars of the sweeps are staged as PAIRS, {delta', u} and {dout, delta' * u}: one
+        // ds_read_b64 each, and both halves of a pair broadcast into v_pk_* through op_sel (a lone scalar in an odd register costs a
+        // v_mov); delta' * u is formed once per element here instead of once per lane and position in each sweep.  The pair tiles
+        // live in the transpose tiles the register channel sums no longer need; su / sg_ are pure output tiles (du, ddelta').
+        v2f *sP1 = reinterpret_cast<v2f *>(sTB), *sP2 = reinterpret_cast<v2f *>(sTC);
         tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
-        tile.put(sg_, rg, nvalid, len);
+        if constexpr (kPk) {
+#pragma unroll
+            for (int k = 0; k < Tile::NE; ++k) {
+                const bool ok = tile.ok(k, nvalid, len);
+                ru[k] = ok ? ru[k] : 0.0f; rg[k] = ok ? rg[k] : 0.0f;
+                const float dlv = sdl[tile.soff(k)];                      // this lane wrote it just above
+                sP1[tile.soff(k)] = (v2f){dlv, ru[k]};
+                sP2[tile.soff(k)] = (v2f){rg[k], dlv * ru[k]};
+            }
+        } else {
+            tile.put(su, ru, nvalid, len);
+            tile.put(sg_, rg, nvalid, len);
+        }
 #pragma unroll
         for (int k = 0; k < Tile::NE; ++k) dDk[Tile::ak(k)] = fmaf(rg[k], ru[k], dDk[Tile::ak(k)]);       // out-of-range elements are zero
         if constexpr (kPk) {
@@ -246,44 +263,42 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 #pragma unroll
             for (int l = 0; l < kCL; ++l) {
                 if ((l & 3) == 0) ckp[l >> 2] = hp;
-                const float dl_ = sdl[l * kPitch + c];
-                const float du_ = dl_ * su[l * kPitch + c];
+                const v2f p1 = sP1[l * kPitch + c], p2 = sP2[l * kPitch + c];      // {delta', u}, {dout, delta' u}
                 const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPk);
-                ap[l] = exp2_pk(splat(dl_) * A2p);
-                hp = pk_fma(ap[l], hp, splat(du_) * Bp);
+                ap[l] = exp2_pk((v2f){p1.x, p1.x} * A2p);
+                hp = pk_fma(ap[l], hp, (v2f){p2.y, p2.y} * Bp);
             }
 #pragma unroll
             for (int kb = NB - 1; kb >= 0; --kb) {
                 const int lb = kb * 4;
-                v2f Bp[4], Cp[4], bu[4], hv[4];
-                float dl4[4], u4[4], g4[4];
+                v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     Bp[j] = *reinterpret_cast<const v2f *>(sBl + (lb + j) * kRPk);
                     Cp[j] = *reinterpret_cast<const v2f *>(sCl + (lb + j) * kRPk);
-                    dl4[j] = sdl[(lb + j) * kPitch + c]; u4[j] = su[(lb + j) * kPitch + c]; g4[j] = sg_[(lb + j) * kPitch + c];
+                    p1[j] = sP1[(lb + j) * kPitch + c]; p2[j] = sP2[(lb + j) * kPitch + c];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bu[j] = splat(dl4[j] * u4[j]) * Bp[j];
+                    bu[j] = (v2f){p2[j].y, p2[j].y} * Bp[j];
                     hv[j] = pk_fma(ap[lb + j], j > 0 ? hv[j > 0 ? j - 1 : 0] : ckp[kb], bu[j]);
                 }
                 float duv[4], ddv[4], vB8[8], vC8[8];
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
-                    const float du_ = dl4[j] * u4[j];
-                    const v2f dhn = pk_fma(Cp[j], splat(g4[j]), dhp);
+                    const v2f gg = {p2[j].x, p2[j].x};
+                    const v2f dhn = pk_fma(Cp[j], gg, dhp);
                     const v2f w = hv[j] - bu[j];                         // = a_j * h_{j-1}
                     const v2f t1 = dhn * Bp[j];
                     const v2f qv = dhn * w;
                     const v2f t2 = qv * Anp;
-                    dAp = pk_fma(qv, splat(dl4[j]), dAp);
-                    const v2f vb = dhn * splat(du_), vc = splat(g4[j]) * hv[j];
+                    dAp = pk_fma(qv, (v2f){p1[j].x, p1[j].x}, dAp);
+                    const v2f vb = dhn * (v2f){p2[j].y, p2[j].y}, vc = gg * hv[j];
                     vB8[2 * j] = vb.x; vB8[2 * j + 1] = vb.y; vC8[2 * j] = vc.x; vC8[2 * j + 1] = vc.y;
                     dhp = ap[lb + j] * dhn;
                     const float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
-                    duv[j] = fmaf(s1, dl4[j], Dv * g4[j]);
-                    ddv[j] = fmaf(s1, u4[j], s2);
+                    duv[j] = fmaf(s1, p1[j].x, Dv * p2[j].x);
+                    ddv[j] = fmaf(s1, p1[j].y, s2);
                 }
                 const float du_t = sum_groups_scatter4<CW>(duv, lane);
                 const float dd_t = sum_groups_scatter4<CW>(ddv, lane);
@@ -292,29 +307,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     su[lo * kPitch + c] = du_t;
                     sg_[lo * kPitch + c] = dd_t;
                 }
-                if constexpr (kDppSums) {
-                    sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
-                    sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
-                } else {
-                    wave_sync();
-#pragma unroll
-                    for (int r = 0; r < 4 * NPL; ++r) {
-                        sTB[(r * SG + sg) * kTP + c] = vB8[r];
-                        sTC[(r * SG + sg) * kTP + c] = vC8[r];
-                    }
-                    wave_sync();
-                    float tb = 0.0f, tc = 0.0f;
-#pragma unroll
-                    for (int k4 = 0; k4 < kQ; ++k4) {
-                        const int q4 = 4 * ((k4 + lane / (16 / kQ)) % kQ);
-                        const float4 x = *reinterpret_cast<const float4 *>(sTB + lane * kTP + q4);
-                        const float4 y = *reinterpret_cast<const float4 *>(sTC + lane * kTP + q4);
-                        tb += (x.x + x.y) + (x.z + x.w);
-                        tc += (y.x + y.y) + (y.z + y.w);
-                    }
-                    sdB[t_out + lb] = tb;
-                    sdC[t_out + lb] = tc;
-                }
+                sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
+                sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
             }
             dhc[0] = dhp.x; dhc[1] = dhp.y; dAacc[0] = dAp.x; dAacc[1] = dAp.y;
         } else {
