@@ -98,7 +98,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
     // packed sweeps: a lane's two states are one v2f; the B / C tiles are laid out [position][state] (pitch kRPk) so that a pair is
     // one ds_read_b64
     // (packed sweeps and register channel sums go together: either alone loses, see MS_BWD_DPP)
-    constexpr bool kPk = MS_BWD_PK && MS_BWD_DPP && NPL == 2 && CW == 8 && !SA && !BCM && MODE == kModeSS2D;
+    constexpr bool kPk = MS_BWD_PK && MS_BWD_DPP && NPL == 2 && CW == 8 && MODE == kModeSS2D;
     constexpr bool kDppSums = kPk;
     constexpr int kRPk = NP + 4;
     const int t_dpp = (sg * NPL + (c & 1)) * kRowPitch + (c >> 1);
@@ -265,7 +265,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 if ((l & 3) == 0) ckp[l >> 2] = hp;
                 const v2f p1 = sP1[l * kPitch + c], p2 = sP2[l * kPitch + c];      // {delta', u}, {dout, delta' u}
                 const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPk);
-                ap[l] = exp2_pk((v2f){p1.x, p1.x} * A2p);
+                if constexpr (SA) { const float a = exp2_fast(p1.x * A2[0]); ap[l] = (v2f){a, a}; }      // one decay per channel
+                else ap[l] = exp2_pk((v2f){p1.x, p1.x} * A2p);
                 hp = pk_fma(ap[l], hp, (v2f){p2.y, p2.y} * Bp);
             }
 #pragma unroll
