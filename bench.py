@@ -33,11 +33,12 @@ import torch.nn as nn
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 # The scan kernels' second ceiling: vector-instruction issue.  Measured on MI355X (tools/microbench/valu_rate.hip,
 # profiles/r02_valu_rate.txt): one wave64 VALU instruction occupies a SIMD for 4.3 cycles (v_fma_f32, v_mul_f32, v_pk_*_f32
-# alike), v_exp_f32 for 8.2; 1024 SIMDs; 2.4 GHz is the chip's maximum clock (under these kernels it holds ~1.6 GHz).
+# alike), v_exp_f32 for 8.2; 1024 SIMDs; 2.4 GHz is the chip's maximum clock (in-kernel measurement: 2.2-2.35 GHz).
 # Wave-level VALU instructions per (channel, state, position) element of the shipped kernels, counted in their ISA
 # (tools/kernel_mix.py): per 32-position chunk of an 8-channel x 16-state wave (64 lanes x 64 elements).
 VALU_CYCLES_PER_INSTR, N_SIMD, MAX_CLOCK_HZ = 4.3, 1024, 2.4e9
-VALU_INSTR_PER_STATE_ELEM = {"scan_bwd": 1711 / 64.0, "scan_fwd": 484 / 64.0}
+# scan_bwd: 1555 since the packed-pair sweeps + register channel sums (round 1 / early round 2: 1711)
+VALU_INSTR_PER_STATE_ELEM = {"scan_bwd": 1555 / 64.0, "scan_fwd": 484 / 64.0}
 
 
 def parse():
