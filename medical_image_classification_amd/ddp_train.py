@@ -159,16 +159,24 @@ class FlatGradDataParallel(nn.Module):
         while self._next >= 0:              # slices held back by a parameter this rank did not use
             self._launch(self._next)
             self._next -= 1
-        self.flags.copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params]))
-        self._works.append(dist.all_reduce(self.flags, async_op=True))
+        local = [p.grad is not None for p in self.params]
+        all_local = all(local)
+        if all_local:
+            self.flags.fill_(1.0)           # no host data: nothing here makes the host wait for the device
+        else:
+            self.flags.copy_(torch.tensor([1.0 if u else 0.0 for u in local]))
+        self._works.append(dist.all_reduce(self.flags, async_op=True))      # every rank contributes its flags, always
         for w in self._works:
-            w.wait()
+            w.wait()                        # stream-level for RCCL: the compute stream waits, the host does not
         self._works, self._armed = [], False
         total = self.flat.numel() - len(self.params)
         self.flat[:total].mul_(1.0 / self.world)
-        used = self.flags.tolist()
+        # A parameter this rank used is used "somewhere": when this rank used ALL of them (the normal case) the reduced flags
+        # need not be read at all -- reading them is a device-to-host copy that would stall the host once per step, and with
+        # ~770 kernels to enqueue per step the GPU then idles while the host catches up.
+        used = local if all_local else [f > 0 for f in self.flags.tolist()]
         for p, v, f in zip(self.params, self.views, used):
-            if f > 0:
+            if f:
                 p.grad = v                  # used on some rank: every rank steps it with the same averaged gradient
             # unused everywhere: grad stays None, the optimizer skips it on all ranks alike
 
