@@ -94,6 +94,11 @@ typedef enum MsStatus {
                                 ms_dtproj_bwd); MsScanBwdParams.ddt_x / ddt_w are reserved for that backward (same addressing
                                 as dB / (dim, dt_rank), accumulated) and are ignored today. */
 
+#define MS_SCAN_DELTA_ACTIVATED 512  /* with MS_SCAN_SOFTPLUS: `delta` already holds delta' = softplus(raw + delta_bias) (ms_dtproj_fwd_act writes
+                                it: the projection kernel is bandwidth-bound, the scan kernels are issue-bound, so the ~13 instructions of
+                                the activation per element sit better there).  Forward and backward use it as is; the backward still
+                                returns the gradient w.r.t. the PRE-activation value (times softplus' = 1 - exp(-delta'), as always) and
+                                ddelta_bias; delta_bias is not read. */
 #define MS_SCAN_LATTICE 256   /* SS2D mode only: the four groups scan the four (row parity, column parity) sub-lattices of the
                                 map_h x map_w map (both even) instead of the four full-resolution directions -- FusionMamba's
                                 stride-2 `EfficientScan` / `EfficientMerge` (CrossMamba/FusionMamba/models/cross.py:139-190,
@@ -271,6 +276,10 @@ int ms_bn_scratch_floats(int C);
  *        workgroups' dWdt partial sums are kept and then added up without atomics; NULL / too small: atomics into dWdt (slower,
  *        same result up to summation order).  Ranks 1..4 use register-tiled kernels, 5..32 scalar-operand kernels (D % 4 == 0). */
 int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npix, int D, int R, int row_width, void *stream);
+/* The same with the activation the scan applies to it folded in: delta'[k, m, d] = softplus(delta[k, m, d] + dt_bias[k, d])
+ * (`dt_projs_bias`, MedMamba.py:403-405), for scans run with MS_SCAN_SOFTPLUS | MS_SCAN_DELTA_ACTIVATED. */
+int ms_dtproj_fwd_act(const float *proj, const float *Wdt, const float *dt_bias, float *delta, int64_t npix, int D, int R, int row_width,
+                      void *stream);
 int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, float *scratch,
                   int64_t scratch_floats, int64_t npix, int D, int R, int row_width, void *stream);
 int64_t ms_dtproj_bwd_scratch_floats(int64_t npix, int D, int R);

@@ -44,7 +44,7 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
                     int out_bf16, int64_t npix, int D, hipStream_t s);
 int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
                     float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
-int dtproj_fwd_dispatch(const float *proj, const float *W, float *delta, int64_t npix, int D, int R, int C, hipStream_t s);
+int dtproj_fwd_dispatch(const float *proj, const float *W, const float *bias, float *delta, int64_t npix, int D, int R, int C, hipStream_t s);
 int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, float *scratch,
                         int64_t scratch_floats, int64_t npix, int D, int R, int C, hipStream_t s);
 int64_t dtproj_bwd_scratch_floats(int64_t npix, int D, int R);
@@ -181,7 +181,13 @@ int ms_layernorm_bwd(const float *x, int64_t x_pixel_stride, const float *gamma,
 }
 
 int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npix, int D, int R, int row_width, void *stream) {
-    return ms::dtproj_fwd_dispatch(proj, Wdt, delta, npix, D, R, row_width, (hipStream_t)stream);
+    return ms::dtproj_fwd_dispatch(proj, Wdt, nullptr, delta, npix, D, R, row_width, (hipStream_t)stream);
+}
+
+int ms_dtproj_fwd_act(const float *proj, const float *Wdt, const float *dt_bias, float *delta, int64_t npix, int D, int R, int row_width,
+                      void *stream) {
+    if (!dt_bias) return MS_ERR_NULL;
+    return ms::dtproj_fwd_dispatch(proj, Wdt, dt_bias, delta, npix, D, R, row_width, (hipStream_t)stream);
 }
 
 int ms_dtproj_bwd(const float *ddelta, const float *proj, const float *Wdt, float *dproj, float *dWdt, float *scratch,

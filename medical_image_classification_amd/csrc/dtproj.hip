@@ -8,8 +8,7 @@
 // x_proj output rows [dts(R) | B(N) | C(N)] per (pixel, direction), ddts is written in place into the same columns of the
 // projection gradient (whose B|C columns the scan backward fills), W lives in registers.
 // One wave = up to 64*VPT channels of one direction, persistent over pixels; lane owns channels lane, lane+64, ...
-#include <hip/hip_runtime.h>
-#include "medscan.h"
+#include "scan_common.h"          // softplus_ref: the SAME function the scan kernels apply (bit-identical delta')
 
 namespace ms {
 
@@ -18,7 +17,7 @@ constexpr int kDtMaxBlocksX = 256;          // persistent workgroups per (direct
 // grid: x = persistent pixel workers, y = 4 directions * ncb channel blocks; block = 4 waves.
 template <int VPT, int RP>
 __global__ void __launch_bounds__(256)
-dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, float *__restrict__ delta,
+dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ delta,
                   int64_t npix, int D, int R, int C, int ncb) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k = blockIdx.y / ncb, cb = blockIdx.y % ncb;
@@ -30,6 +29,9 @@ dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, f
 #pragma unroll
         for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
     }
+    float bv[VPT];                               // bias != NULL: delta' = softplus(delta + bias[k, d]) (MS_SCAN_DELTA_ACTIVATED)
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) bv[j] = (bias && dbase + lane + 64 * j < D) ? bias[(int64_t)k * D + dbase + lane + 64 * j] : 0.0f;
     float *dk = delta + (int64_t)k * npix * D;
     constexpr int PB = 8;                       // pixels per wave (one trip: nothing to accumulate, the hardware overlaps waves)
     const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB;
@@ -51,6 +53,7 @@ dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, f
                 float a = 0.0f;
 #pragma unroll
                 for (int r = 0; r < RP; ++r) a = fmaf(t[q][r], w[j][r], a);
+                if (bias) a = softplus_ref(a + bv[j]);
                 if (dbase + lane + 64 * j < D) o[q * D + 64 * j] = a;
             }
         }
@@ -177,7 +180,7 @@ dtproj_bwd_kernel(const float *__restrict__ ddelta, const float *__restrict__ pr
 // ddelta is read twice (once per backward product); at these ranks it fits the 256 MB MALL.
 template <int VPT, int RP>
 __global__ void __launch_bounds__(256)
-dtproj_fwd_s_kernel(const float *__restrict__ proj, const float *__restrict__ W, float *__restrict__ delta,
+dtproj_fwd_s_kernel(const float *__restrict__ proj, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ delta,
                     int64_t npix, int D, int R, int C, int ncb, int ppw) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = blockIdx.y / ncb, cb = blockIdx.y % ncb;
@@ -189,6 +192,9 @@ dtproj_fwd_s_kernel(const float *__restrict__ proj, const float *__restrict__ W,
 #pragma unroll
         for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
     }
+    float bv[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) bv[j] = (bias && dbase + lane + 64 * j < D) ? bias[(int64_t)k * D + dbase + lane + 64 * j] : 0.0f;
     float *dk = delta + (int64_t)k * npix * D + dbase + lane;
     const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * ppw;
     const int64_t p1 = p0 + ppw < npix ? p0 + ppw : npix;
@@ -203,6 +209,7 @@ dtproj_fwd_s_kernel(const float *__restrict__ proj, const float *__restrict__ W,
             float a = 0.0f;
 #pragma unroll
             for (int r = 0; r < RP; ++r) a = fmaf(t[r], w[j][r], a);
+            if (bias) a = softplus_ref(a + bv[j]);
             if (dbase + lane + 64 * j < D) dk[p * D + 64 * j] = a;
         }
     }
@@ -386,7 +393,7 @@ static int launch_dt(bool bwd, const float *a, const float *proj, const float *W
     const dim3 grid((unsigned)(blocks < 1 ? 1 : blocks), (unsigned)(4 * ncb)), block(256);
 #define MS_DT(V)                                                                                                         \
     if (bwd) hipLaunchKernelGGL((dtproj_bwd_kernel<V, RP>), grid, block, 0, s, a, proj, W, o1, o2, npix, D, R, C, ncb);    \
-    else hipLaunchKernelGGL((dtproj_fwd_kernel<V, RP>), grid, block, 0, s, proj, W, o1, npix, D, R, C, ncb)
+    else hipLaunchKernelGGL((dtproj_fwd_kernel<V, RP>), grid, block, 0, s, proj, W, a, o1, npix, D, R, C, ncb)
     switch (vpt) {
         case 1: MS_DT(1); break;
         case 2: MS_DT(2); break;
@@ -417,8 +424,8 @@ static int launch_dt_s(bool bwd, const float *a, const float *proj, const float 
     if (!bwd) {
         const int ppw = npix >= 32768 ? 64 : 16;                 // few pixels: more, shorter waves
         const dim3 grid((unsigned)((npix + 4 * ppw - 1) / (4 * ppw)), (unsigned)(4 * ncb));
-        if (vpt == 2) hipLaunchKernelGGL((dtproj_fwd_s_kernel<2, RP>), grid, dim3(256), 0, s, proj, W, o1, npix, D, R, C, ncb, ppw);
-        else          hipLaunchKernelGGL((dtproj_fwd_s_kernel<1, RP>), grid, dim3(256), 0, s, proj, W, o1, npix, D, R, C, ncb, ppw);
+        if (vpt == 2) hipLaunchKernelGGL((dtproj_fwd_s_kernel<2, RP>), grid, dim3(256), 0, s, proj, W, a, o1, npix, D, R, C, ncb, ppw);
+        else          hipLaunchKernelGGL((dtproj_fwd_s_kernel<1, RP>), grid, dim3(256), 0, s, proj, W, a, o1, npix, D, R, C, ncb, ppw);
         return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
     }
     // ddts: 64 pixels x 256 channels per workgroup
@@ -460,9 +467,11 @@ static int dt_dispatch(bool bwd, const float *a, const float *proj, const float 
     }
 }
 
-int dtproj_fwd_dispatch(const float *proj, const float *W, float *delta, int64_t npix, int D, int R, int C, hipStream_t s) {
+// bias (4, D) or NULL: forward `a` operand of dt_dispatch = the activation's bias (delta' = softplus(delta + bias))
+int dtproj_fwd_dispatch(const float *proj, const float *W, const float *bias, float *delta, int64_t npix, int D, int R, int C,
+                        hipStream_t s) {
     if (!proj || !W || !delta) return MS_ERR_NULL;
-    return dt_dispatch(false, nullptr, proj, W, delta, nullptr, nullptr, 0, npix, D, R, C, s);
+    return dt_dispatch(false, bias, proj, W, delta, nullptr, nullptr, 0, npix, D, R, C, s);
 }
 
 int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, float *scratch,

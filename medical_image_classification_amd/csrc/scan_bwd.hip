@@ -222,7 +222,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
         // v_mov); delta' * u is formed once per element here instead of once per lane and position in each sweep.  The pair tiles
         // live in the transpose tiles the register channel sums no longer need; su / sg_ are pure output tiles (du, ddelta').
         v2f *sP1 = reinterpret_cast<v2f *>(sTB), *sP2 = reinterpret_cast<v2f *>(sTC);
-        tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len);
+        tile.put_delta(sdl, rd, sbias, sp_mask, nvalid, len, (p.delta_softplus & MS_SCAN_DELTA_ACTIVATED) != 0);
         if constexpr (kPk) {
 #pragma unroll
             for (int k = 0; k < Tile::NE; ++k) {

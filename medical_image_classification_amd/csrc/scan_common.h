@@ -179,8 +179,14 @@ struct TileIO {
     }
     // delta tile: bias + softplus applied once per element on the way into LDS (sp_mask = all ones / zero:
     // a bit-select instead of a branch per element)
+    // pre: the values are already activated (MS_SCAN_DELTA_ACTIVATED) -- wave-uniform, so a real branch skips the work
     __device__ __forceinline__ void put_delta(float *s, const float (&r)[NE], const float *sbias, unsigned sp_mask,
-                                              int nvalid, int len) const {
+                                              int nvalid, int len, bool pre = false) const {
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) s[soff(k)] = ok(k, nvalid, len) ? r[k] : 0.0f;
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const float raw = r[k] + sbias[ck(k)];

@@ -153,11 +153,15 @@ scan_fwd_kernel(const MsScanParams p, const int n_chunks, const int ncb) {
         __syncthreads();                                    // everyone is done with the previous chunk's shared B/C tiles
         // stage {delta', delta' * u}: bias + softplus once per element (a bit-select instead of a branch); elements
         // past the tile edge become the scan identity (a, b) = (1, 0) -- selective_scan_fwd_kernel.cuh:218-222
+        const bool pre = (p.delta_softplus & MS_SCAN_DELTA_ACTIVATED) != 0;      // delta' arrives activated (wave-uniform branch)
 #pragma unroll
         for (int k = 0; k < Tile::NE; ++k) {
             const bool ok = tile.ok(k, nvalid, len);
-            const float raw = rd[k] + sbias[tile.ck(k)];
-            const float sp = bits_f((f_bits(softplus_ref(raw)) & sp_mask) | (f_bits(raw) & ~sp_mask));
+            float sp = rd[k];
+            if (!pre) {
+                const float raw = rd[k] + sbias[tile.ck(k)];
+                sp = bits_f((f_bits(softplus_ref(raw)) & sp_mask) | (f_bits(raw) & ~sp_mask));
+            }
             const float dl = ok ? sp : 0.0f;
             uk[k] = ok ? ru[k] : 0.0f;
             sdd[tile.soff(k)] = (v2f){dl, dl * uk[k]};

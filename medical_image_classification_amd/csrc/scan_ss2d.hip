@@ -106,12 +106,14 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
         A2[i / 2][i % 2] = av * kLog2e;
         h[i / 2][i % 2] = 0.0f;
     }
+    // MS_SCAN_DELTA_ACTIVATED: delta already holds softplus(raw + bias) (ms_dtproj_fwd_act); wave-uniform
+    const bool pre = !DTF && (p.delta_softplus & MS_SCAN_DELTA_ACTIVATED) != 0;
     float D4[4], bias4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int dj = min(d0 + my4 + j, p.dim - 1);
         D4[j] = (p.D && quad_ok) ? p.D[dj] : 0.0f;
-        bias4[j] = (p.delta_bias && quad_ok) ? p.delta_bias[dj] : 0.0f;
+        bias4[j] = (p.delta_bias && quad_ok && !pre) ? p.delta_bias[dj] : 0.0f;
     }
     if (DTF) {          // Wdt rows of the workgroup's channels -> LDS, transposed to [r][channel]
         for (int e = tid; e < 32 * R; e += NT) {
@@ -211,7 +213,9 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
             float dl[4], us[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float sp = bits_f((f_bits(softplus_ref(raw[j])) & sp_mask) | (f_bits(raw[j]) & ~sp_mask));
+                float sp;
+                if (!DTF && pre) sp = raw[j];                            // delta' arrives activated (bias4 == 0: raw is the loaded value)
+                else sp = bits_f((f_bits(softplus_ref(raw[j])) & sp_mask) | (f_bits(raw[j]) & ~sp_mask));
                 dl[j] = ok ? sp : 0.0f;
                 us[j] = ok ? uu[j] : 0.0f;
             }

@@ -77,7 +77,9 @@ def _refresh(reg, device):
     reg.params = live
     if not todo:
         return
-    key = tuple((p.data_ptr(), sh.t.data_ptr()) for p, sh in todo)
+    # the cached descriptor table is valid only for EXACTLY these tensors: pointers alone are not enough -- the caching allocator
+    # hands a freed parameter's address to the next model, whose tensor of another size would then be cast with the old extent
+    key = tuple((p.data_ptr(), sh.t.data_ptr(), p.numel(), tuple(p.shape) if sh.conv else 0) for p, sh in todo)
     if reg.table is None or reg.table[0] != key:
         arr = (MsCastDesc * len(todo))()
         biggest = 1

@@ -105,18 +105,32 @@ def _split_k(M):
     return 1
 
 
-def _dtproj_fwd(proj, wdt, B, L, D, R, C):
+_DT_ACT = os.environ.get("MEDSCAN_DT_ACTIVATED", "1") == "1"
+
+
+def _dtproj_fwd(proj, wdt, B, L, D, R, C, act_bias=None):
     """delta (4,B,L,D) = dts @ Wdt^T (MedMamba.py:400), fp32, with dts = the first R columns of the projection rows:
-    ms_dtproj_fwd (reads them in place) for small ranks, one batched GEMM otherwise.  Runs inside the scan's autograd
-    node, so neither the dts slice nor delta ever becomes an autograd tensor."""
+    ms_dtproj_fwd (reads them in place), one batched GEMM above _DT_KERNEL_MAX_RANK.  Runs inside the scan's autograd
+    node, so neither the dts slice nor delta ever becomes an autograd tensor.
+    act_bias (4*D,): ms_dtproj_fwd_act -- the kernel (bandwidth-bound) also applies delta' = softplus(delta + bias), which the
+    issue-bound scan kernels then skip (MS_SCAN_DELTA_ACTIVATED); only the kernel path can, so callers check `_dt_act_ok(R)`."""
     M = B * L
     if R <= _DT_KERNEL_MAX_RANK:
         delta = torch.empty((4, B, L, D), device=proj.device, dtype=torch.float32)
-        _lib.check(_lib.lib().ms_dtproj_fwd(proj.data_ptr(), wdt.data_ptr(), delta.data_ptr(), M, D, R, C,
-                                            _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd")
+        if act_bias is not None:
+            _lib.check(_lib.lib().ms_dtproj_fwd_act(proj.data_ptr(), wdt.data_ptr(), act_bias.data_ptr(), delta.data_ptr(), M, D, R, C,
+                                                    _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd_act")
+        else:
+            _lib.check(_lib.lib().ms_dtproj_fwd(proj.data_ptr(), wdt.data_ptr(), delta.data_ptr(), M, D, R, C,
+                                                _lib.current_stream_ptr(proj.device)), "ms_dtproj_fwd")
         return delta
+    assert act_bias is None
     dts = proj.view(M, 4, C)[:, :, :R].permute(1, 0, 2)          # (4, M, R) view: row stride 4C, unit inner stride -- a valid GEMM operand
     return torch.bmm(dts, wdt.transpose(1, 2)).view(4, B, L, D)
+
+
+def _dt_act_ok(R):
+    return _DT_ACT and R <= _DT_KERNEL_MAX_RANK
 
 
 def _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C):
@@ -352,9 +366,12 @@ class _SS2DInner(torch.autograd.Function):
             # inference (no gradient wanted): the Delta projection is formed inside the scan kernel (MS_SCAN_DT_FUSED) --
             # no dt_proj launch, no delta tensor, no saved states.  Training materialises delta: the backward kernel reads it.
             fuse_dt = (not any(ctx.needs_input_grad)) and N == 16 and R <= 32 and D % 4 == 0
-            delta = None if fuse_dt else _dtproj_fwd(proj, wdt, B, L, D, R, C)
+            act = (not fuse_dt) and _dt_act_ok(R)          # delta' = softplus(delta + bias) formed by the projection kernel
+            delta = None if fuse_dt else _dtproj_fwd(proj, wdt, B, L, D, R, C, act_bias=bias if act else None)
             P = MsScanParams()
             _ss2d_params(P, xc, proj, delta, A, Dv, bias, y4, x_state, H, W, N, R, a_is_log=True)
+            if act:
+                P.delta_softplus |= 512             # MS_SCAN_DELTA_ACTIVATED
             if fuse_dt:
                 P.delta_softplus |= 128             # MS_SCAN_DT_FUSED
                 P.dt_x, P.dt_w, P.dt_rank, P.x = proj.data_ptr(), wdt.data_ptr(), R, None
@@ -367,7 +384,7 @@ class _SS2DInner(torch.autograd.Function):
         ctx.save_for_backward(xz, xc, xm if (mm_dtype is not None and not mfma) else None, wx, proj, delta, x_state, y4, cw, cb, wdt,
                               A, Dv, bias, gamma, beta)
         ctx.geom = (N, R, float(eps))
-        ctx.mfma = mfma
+        ctx.mfma, ctx.act = mfma, act
         ctx.dtypes = (conv_w.dtype, conv_b.dtype if conv_b is not None else None, xproj_w.dtype, xproj_w.shape)
         return out
 
@@ -395,6 +412,8 @@ class _SS2DInner(torch.autograd.Function):
         dA, dD, dbias, dgamma, dbeta, dcw, dcb = zbuf.split(sizes)
         Q = MsScanBwdParams()
         _ss2d_params(Q.f, xc, proj, delta, A, Dv, bias, None, x_state, H, W, N, R, a_is_log=True)
+        if ctx.act:
+            Q.f.delta_softplus |= 512               # MS_SCAN_DELTA_ACTIVATED: `delta` holds delta'
         Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * D, 0, 1, D
         Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * D, B * L * D, 1, D
         Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * D, B * L * D, 1, D

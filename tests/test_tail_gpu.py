@@ -264,3 +264,31 @@ def test_batchnorm_backward_writes_dx_in_the_input_dtype():
     yr.backward(g.float())
     assert x.grad.dtype == torch.float32
     np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(2, 56, 56, 96, 3), (2, 14, 14, 384, 12), (1, 9, 7, 48, 5)])
+def test_activation_inside_the_dt_projection_is_bit_identical(cfg, monkeypatch):
+    """ms_dtproj_fwd_act + MS_SCAN_DELTA_ACTIVATED (delta' = softplus(delta + bias) formed by the bandwidth-bound projection kernel,
+    skipped by the issue-bound scan kernels) against the scan applying it itself: the same function on the same values, so the
+    outputs and every gradient agree bit for bit (up to the order of the atomics in the reductions)."""
+    from medical_image_classification_amd import ss2d_fused
+    from medical_image_classification_amd.medmamba import SS2D
+    B, H, W, D, R = cfg
+    torch.manual_seed(9)
+    mod = SS2D(d_model=D // 2, d_state=16, dt_rank=R).to(dev()).train()
+    x0 = torch.randn(B, H, W, D // 2, device=dev())
+    g = torch.randn(B, H, W, D // 2, device=dev())
+    res = []
+    for act in (True, False):
+        monkeypatch.setattr(ss2d_fused, "_DT_ACT", act)
+        for p in mod.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        y = mod(x)
+        y.backward(g)
+        res.append((y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()}))
+    (ya, dxa, ga), (yb, dxb, gb) = res
+    assert torch.equal(ya, yb)
+    np.testing.assert_allclose(dxa.cpu().numpy(), dxb.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(dxb.abs().max()))
+    for n in ga:
+        np.testing.assert_allclose(ga[n].cpu().numpy(), gb[n].cpu().numpy(), rtol=1e-4, atol=1e-5 * float(gb[n].abs().max()) + 1e-12, err_msg=n)
