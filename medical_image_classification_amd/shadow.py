@@ -65,12 +65,13 @@ def _stale(p, sh, epoch):
 
 
 def _refresh(reg, device):
-    live, todo = [], []
+    live, todo, seen = [], [], set()
     for pid in reg.params:
         sh = _BY_ID.get(pid)
         p = sh.owner() if sh is not None else None
-        if p is None:
+        if p is None or pid in seen:                # dead, or an id the interpreter has recycled for a newer parameter
             continue
+        seen.add(pid)
         live.append(pid)
         if p.is_cuda and p.device == device and sh.t.device == device and _stale(p, sh, reg.epoch):
             todo.append((p, sh))
