@@ -126,6 +126,11 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
     constexpr int TNT = BN / 16, MT = BM / 64;
     __shared__ __attribute__((aligned(16))) unsigned short sA[TileStage<BM, AF32, ATR>::kLds];
     __shared__ __attribute__((aligned(16))) unsigned short sB[TileStage<BN, BF32, BTR>::kLds];
+    // accumulating modes: the workgroup's fp32 tile goes through LDS so that a wave's atomics cover 64 CONSECUTIVE addresses (the
+    // MFMA layout would scatter them over 16 rows) and start at a position that depends on the k-slice (concurrent slices of one
+    // output tile then hit different addresses instead of queueing on the same ones)
+    constexpr int kCP = BN + 1;
+    __shared__ float sCt[CMODE >= 2 ? BM * kCP : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
@@ -176,6 +181,30 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
     for (int k0 = kbeg; k0 < kend; k0 += 2 * kBK) {
         step(ta[0], tb[0], k0);
         if (k0 + kBK < kend) step(ta[1], tb[1], k0 + kBK);
+    }
+    if constexpr (CMODE >= 2) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int a = 0; a < TNT; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sCt[(w * (16 * MT) + b * 16 + fr) * kCP + a * 16 + fq * 4 + r] = acc[a][b][r];
+        __syncthreads();
+        constexpr int kTot = BM * BN;
+        const int rot = (int)(blockIdx.z % (kTot / 256)) * 256;
+        float *Cf = static_cast<float *>(C);
+        for (int i = 0; i < kTot / 256; ++i) {
+            const int e = (i * 256 + tid + rot) % kTot;
+            int ml, nl;
+            if (CMODE == 2) { nl = e % BN; ml = e / BN; }            // consecutive threads along n: rows of C
+            else            { ml = e % BM; nl = e / BM; }            // consecutive threads along m: rows of C^T
+            const int m = m0 + ml, n = n0 + nl;
+            if (m < M && n < N) {
+                const float v = sCt[ml * kCP + nl];
+                atomicAdd(CMODE == 2 ? Cf + (int64_t)m * ldc + n : Cf + (int64_t)n * ldc + m, v);
+            }
+        }
+        return;
     }
     // D[i][j]: i = n within the tile (row 4*fq + r of the accumulator), j = m within the tile (column fr)
 #pragma unroll
