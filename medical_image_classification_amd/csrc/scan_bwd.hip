@@ -459,8 +459,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                 const int isC = idx / (NP * kCL), rem = idx % (NP * kCL);
                 int n, l;
                 if (MODE == kModeSS2D) {            // (n, tensor) fastest: dB|dC of a pixel are adjacent in the projection row
-                    const int t = idx % (2 * NP); l = idx / (2 * NP); n = t % NP;
-                    if ((t >= NP) != (isC != 0)) { /* remap: idx enumerates (l, tensor, n) in SS2D mode */ }
+                    const int t = idx % (2 * NP); l = idx / (2 * NP); n = t % NP;            // idx enumerates (l, tensor, n) here
                     const int tc = t >= NP;
                     float v = 0.0f;
 #pragma unroll
