@@ -9,8 +9,8 @@ in device memory; convolution weights are written in channels_last order directl
 A copy is stale when the parameter's version counter or data pointer changed (`load_state_dict`, in-place updates under
 no_grad, `.to()` bump / change them) or when `invalidate()` was called since.  The version counter alone is NOT enough: fused
 optimizers (`torch.optim.Adam(fused=True)`) and writes through `p.data` do not bump it -- so every autograd.Function that uses
-a copy calls `invalidate()` from its backward (weights only change after a backward pass), and VSSM.forward does so once per
-training step as well.  The copies carry no autograd history: the caller's autograd.Function returns the gradient for the
+a copy calls `invalidate()` from its backward, a process-wide optimizer post-step hook does the same after EVERY
+`Optimizer.step()`, and VSSM.forward does so once per training step as well.  The copies carry no autograd history: the caller's autograd.Function returns the gradient for the
 fp32 master itself.  MEDSCAN_BF16_SHADOWS=0 turns the cache off (every request casts).
 """
 import ctypes
@@ -58,6 +58,16 @@ def invalidate(device=None):
     for idx, r in _REG.items():
         if device is None or device.index is None or device.index == idx:
             r.epoch += 1
+
+
+# Every optimizer step of the process invalidates the copies too (fused optimizers update parameters without bumping their
+# version counters): together with the invalidation from the backward of every Function that used a copy, no training loop can
+# see a stale weight, whatever its order of forward / backward / step.
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    register_optimizer_step_post_hook(lambda _opt, _args, _kwargs: invalidate())
+except Exception:          # pragma: no cover  (an old torch without global optimizer hooks: the backward invalidation remains)
+    pass
 
 
 def _stale(p, sh, epoch):

@@ -49,8 +49,12 @@ def test_bf16_weight_copies_one_launch_refresh_and_staleness():
     assert not torch.equal(shadow._BY_ID[id(ps[1])].t, want(ps[1], False))
     shadow.invalidate(dev())
     assert torch.equal(shadow.bf16(ps[1]), want(ps[1], False))
-    # a fused optimizer step does NOT bump the version counters: the copies are invalidated by the backward of every Function
-    # that used one (here: a convolution through the cached weight), so the step after a backward always refreshes
+    # a fused optimizer step does NOT bump the version counters: a process-wide optimizer post-step hook invalidates the copies
+    fo = torch.optim.Adam([ps[4]], lr=0.1, fused=True)
+    ps[4].grad = torch.ones_like(ps[4])
+    fo.step()
+    assert torch.equal(shadow.bf16(ps[4], conv=True), want(ps[4], True))
+    # ... and so does the backward of every Function that used one (here: a convolution through the cached weight)
     from medical_image_classification_amd.block_ops import _conv2d
     conv = nn.Conv2d(48, 48, 3, padding=1).to(dev())
     opt = torch.optim.Adam(conv.parameters(), lr=0.1, fused=True)
