@@ -33,31 +33,6 @@ constexpr int kWPB = 4;      // waves per workgroup in the backward: independent
                          // scalar + LDS 5.94 | scalar + DPP 6.17 | packed + LDS 6.20 | packed + DPP 5.42.  Either change alone loses
                          // (more VALU for the DPP sums / the LDS pipe becomes the bound once the VALU work shrinks); together they win.
 #endif
-// Sum over the wave's 8 channel lanes (lane bits 0-2) of the 8 (position, state) values of a batch, scattered: lane c ends up
-// with the total of v[c].  Pure VALU (DPP row_ror / quad_perm adds + selects, 21 instructions): replaces a transpose through a
-// wave-private LDS tile (16 ds_write_b32 + 4 ds_read_b128 and two dependent LDS round trips per batch and tensor).
-// The lane-bit-2 step needs no select: two DPP adds write disjoint bank sets of one register (banks 0, 2 = lanes with bit 2
-// clear read lane + 4 through row_ror:12; banks 1, 3 read lane - 4 through row_ror:4).  Inline assembly: the builtin only offers
-// the move form.  s_nop 1 = the two wait states a DPP read of a just-written VGPR needs (the compiler's hazard recognizer does
-// not look inside asm blocks).
-__device__ __forceinline__ float chan_scatter8(const float (&v)[8], int lane) {
-    float a0, a1, a2, a3;
-    // one block for the four (v[q], v[q+4]) pairs: a single s_nop covers the freshest input, the DPP adds are independent
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %1, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %2, %6, %6 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %3, %7, %7 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-                 "v_add_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-                 "v_add_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-                 "v_add_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa"
-                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-    const float b0 = xchg_add<2>(a0, a2, lane), b1 = xchg_add<2>(a1, a3, lane);
-    return xchg_add<1>(b0, b1, lane);
-}
-
 // SA: scalar decay per channel (A_dstate_stride == 0, the SSD form): one exp2 and one stored decay per position.
 // BCM: the B/C rows and the dB/dC flush follow the pixel order of one fixed direction (MS_SCAN_BC_MAP, see scan_fwd.hip).
 template <int NPL, int CW, int MODE, bool SA = false, bool BCM = false>
@@ -538,6 +513,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 
 int validate_scan(const MsScanParams &p);
 int scan_positions(const MsScanParams &p);
+int ssd_bwd_all_launch(const MsScanBwdParams &q, int n_chunks, hipStream_t stream);
 int pick_npl(int dstate, int sg);
 bool use_cw8(const MsScanParams &p, bool backward);
 int pick_mode(bool l_contig, bool d_contig, bool small, int map_h);
@@ -591,6 +567,16 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
     if (n_chunks > 1 && !p.x) return MS_ERR_NULL;
+    if (((p.delta_softplus >> 4) & 7) - 1 == 4) {
+        // MS_SCAN_BC_MAP(4): all four direction slices of the SSD state axis in one launch (scan_bwd_ssd.hip)
+        if (p.map_h <= 0 || p.A_dstate_stride != 0 || p.dstate % 4 != 0 || p.dstate / 4 > 16 || p.n_groups % 4 != 0 ||
+            (p.delta_softplus & (MS_SCAN_ACCUMULATE | MS_SCAN_LATTICE)) || q.dout_d_stride != 1)
+            return MS_ERR_SHAPE;
+        if (!fits24(p.seqlen) || !fits24(p.u_l_stride) || !fits24(p.delta_l_stride) || !fits24(q.dout_l_stride) || !fits24(q.du_l_stride) ||
+            !fits24(q.ddelta_l_stride) || !fits24(p.B_l_stride) || !fits24(p.C_l_stride) || !fits24(q.dB_l_stride) || !fits24(q.dC_l_stride))
+            return MS_ERR_STRIDE;
+        return ssd_bwd_all_launch(q, n_chunks, stream);
+    }
     if (use_cw8(p, true)) {
         switch (pick_npl(p.dstate, 8)) {
             case 1: return launch_bwd<1, 8>(q, n_chunks, stream);

@@ -338,6 +338,31 @@ __device__ __forceinline__ float sum_groups_scatter4(const float (&v)[4], int la
     if constexpr (CW == 8) r += dpp_mov<0x128>(r);          // third group bit (lane bit 3): plain butterfly add
     return r;
 }
+// Sum over the wave's 8 channel lanes (lane bits 0-2) of the 8 (position, state) values of a batch, scattered: lane c ends up
+// with the total of v[c].  Pure VALU (DPP row_ror / quad_perm adds + selects, 21 instructions): replaces a transpose through a
+// wave-private LDS tile (16 ds_write_b32 + 4 ds_read_b128 and two dependent LDS round trips per batch and tensor).
+// The lane-bit-2 step needs no select: two DPP adds write disjoint bank sets of one register (banks 0, 2 = lanes with bit 2
+// clear read lane + 4 through row_ror:12; banks 1, 3 read lane - 4 through row_ror:4).  Inline assembly: the builtin only offers
+// the move form.  s_nop 1 = the two wait states a DPP read of a just-written VGPR needs (the compiler's hazard recognizer does
+// not look inside asm blocks).
+__device__ __forceinline__ float chan_scatter8(const float (&v)[8], int lane) {
+    float a0, a1, a2, a3;
+    // one block for the four (v[q], v[q+4]) pairs: a single s_nop covers the freshest input, the DPP adds are independent
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+    const float b0 = xchg_add<2>(a0, a2, lane), b1 = xchg_add<2>(a1, a3, lane);
+    return xchg_add<1>(b0, b1, lane);
+}
+
 template <int CW> __device__ __forceinline__ int group_slot(int lane) { return lane >> 4; }          // = lane bits 5,4
 template <int CW> __device__ __forceinline__ bool is_group_owner(int lane) { return CW == 16 || (lane & 8) == 0; }
 

@@ -576,18 +576,22 @@ class _SSDScanMerge(torch.autograd.Function):
         *dA_w, dD, dbias = zbuf.split(sizes)
         dA_of = dict(zip(widths, dA_w))
         stream = _lib.current_stream_ptr(xc.device)
+        # all four direction slices in ONE launch (MS_SCAN_BC_MAP(4), csrc/scan_bwd_ssd.hip) when the forward ran that way too
+        # (same slice-major saved states); otherwise one launch per slice, accumulating
+        one = N == _SSD_SLICE and SSD_ONE_LAUNCH_FWD and SSD_ONE_LAUNCH_BWD
+        launches = [(4, 0, 4 * N)] if one else _ssd_slices(N)
         with _lib.on_device(xc.device):
-            for i, (j, s0, ns) in enumerate(_ssd_slices(N)):
+            for i, (j, s0, ns) in enumerate(launches):
                 Q = MsScanBwdParams()
-                _ssd_params(Q.f, xc, delta, A_col, D_full if i == 0 else None, bias_full, None, x_state[i], B, L, H, W, Ds, N, conv,
-                            j, s0, ns, i > 0)
+                _ssd_params(Q.f, xc, delta, A_col, D_full if i == 0 else None, bias_full, None, x_state if one else x_state[i], B, L, H, W,
+                            Ds, N, conv, j, s0, ns, i > 0)
                 Q.dout_batch_stride, Q.dout_group_stride, Q.dout_d_stride, Q.dout_l_stride = L * Ds, 0, 1, Ds
                 Q.du_batch_stride, Q.du_group_stride, Q.du_d_stride, Q.du_l_stride = L * Ds, B * L * Ds, 1, Ds
                 Q.ddelta_batch_stride, Q.ddelta_group_stride, Q.ddelta_d_stride, Q.ddelta_l_stride = L * Ds, B * L * Ds, 1, Ds
                 Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride, Q.dB_l_stride = L * conv, 0, 1, conv
                 Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride, Q.dC_l_stride = L * conv, 0, 1, conv
                 Q.dout, Q.du, Q.ddelta = dy.data_ptr(), du4.data_ptr(), dd4.data_ptr()
-                Q.dA, Q.ddelta_bias = dA_of[ns].data_ptr(), dbias.data_ptr()
+                Q.dA, Q.ddelta_bias = dA_of[N if one else ns].data_ptr(), dbias.data_ptr()
                 Q.dD = dD.data_ptr() if i == 0 else None
                 Q.dB, Q.dC = dxc.data_ptr() + 4 * (Ds + s0), dxc.data_ptr() + 4 * (Ds + N + s0)
                 rc = TIMER.launch("scan_bwd", algorithmic_bytes(B, 4 * Ds, L, ns, 4, True), xc.device,
@@ -603,6 +607,7 @@ class _SSDScanMerge(torch.autograd.Function):
 
 _SSD_SLICE = 16      # states per backward launch (the backward kernels keep <= 16 states of a channel in registers)
 SSD_ONE_LAUNCH_FWD = os.environ.get("MEDSCAN_SSD_ONE_LAUNCH_FWD", "1") == "1"
+SSD_ONE_LAUNCH_BWD = os.environ.get("MEDSCAN_SSD_ONE_LAUNCH_BWD", "1") == "1"
 
 
 def _ssd_slices(N):

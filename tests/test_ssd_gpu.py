@@ -469,3 +469,31 @@ def test_vfefm_fusion_step_at_224():
             used += 1
     assert used > 1000
     assert not torch.equal(before, net.final_conv.weight.detach())
+
+
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 4, 16), (1, 9, 5, 32, 2, 16), (2, 28, 28, 96, 3, 32)])
+def test_ssd_backward_all_slices_in_one_launch(cfg, monkeypatch):
+    """ms_selective_scan_bwd with MS_SCAN_BC_MAP(4) (csrc/scan_bwd_ssd.hip: the four direction slices of the state axis in one
+    launch) against one accumulating launch per slice: every gradient of the 4-direction SSD scan."""
+    from medical_image_classification_amd import ss2d_fused
+    B, H, W, Ds, nheads, headdim = cfg
+    N = 16
+    assert nheads * headdim == Ds
+    gen = torch.Generator().manual_seed(21)
+    conv = Ds + 2 * N + nheads
+    xc0 = torch.randn(B, H, W, conv, generator=gen).cuda()
+    As0 = -(torch.rand(4 * nheads, generator=gen) + 0.5).cuda()
+    Dsv0 = torch.randn(4 * nheads, generator=gen).cuda()
+    bias0 = (torch.rand(4 * nheads, generator=gen) - 3.0).cuda()
+    gy = torch.randn(B, H * W, Ds, generator=gen).cuda()
+    res = []
+    for one in (True, False):
+        monkeypatch.setattr(ss2d_fused, "SSD_ONE_LAUNCH_BWD", one)
+        ts = [t.clone().requires_grad_() for t in (xc0, As0, Dsv0, bias0)]
+        y = ss2d_fused._SSDScanMerge.apply(ts[0], ts[1], ts[2], ts[3], H, W, Ds, N, nheads, headdim, False)
+        y.backward(gy)
+        res.append((y.detach(), [t.grad for t in ts]))
+    (ya, ga), (yb, gb) = res
+    assert torch.equal(ya, yb)
+    for a, b, name in zip(ga, gb, ("dxc", "dA", "dD", "dbias")):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(b.abs().max()), err_msg=name)
