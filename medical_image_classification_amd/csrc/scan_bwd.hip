@@ -18,6 +18,10 @@
 // the per-(l,n) dB/dC contributions are summed over the wave's CW channels by a transpose through a wave-private
 // LDS tile (conflict-free b32 writes, b128 row reads), then over the workgroup's 4 waves, then added to global
 // memory with atomics.
+// The benchmark's instantiation (2 states per lane, 8-channel waves, SS2D mode) takes the PACKED path (`kPk`): state pairs as
+// v2f through v_pk_* in both sweeps, the per-position scalars staged as pairs, and the channel sums as a register reduce-scatter
+// (banked DPP adds, scan_common.h chan_scatter8) instead of the LDS transpose -- MS_BWD_PK / MS_BWD_DPP below, DESIGN.md 3.3.
+// The SSD blocks' backward over all four direction slices in one launch is its own kernel: scan_bwd_ssd.hip.
 #include "scan_common.h"
 
 namespace ms {
