@@ -334,7 +334,9 @@ int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda,
  * NHWC path) around MedMamba.py:517-527 and :284,326.  `desc`: n_tensors descriptors IN DEVICE MEMORY.
  *   taps <= 1 : dst[e] = bf16(src[e]), e < n
  *   taps  > 1 : a (O, inner, kh, kw) convolution weight, taps = kh*kw, written in channels_last memory order (O, kh, kw, inner):
- *               dst[(o*taps + k)*inner + i] = bf16(src[(o*inner + i)*taps + k]),  n = O*inner*taps */
+ *               dst[(o*taps + k)*inner + i] = bf16(src[(o*inner + i)*taps + k]),  n = O*inner*taps
+ *   taps  < 0 : the same weight for the INPUT-GRADIENT convolution, |taps| spatially flipped and in / out channels swapped, memory
+ *               order (inner, kh, kw, O):  dst[(i*T + (T-1-k))*O + o] = bf16(src[(o*inner + i)*T + k]),  T = |taps| */
 typedef struct MsCastDesc {
     const void *src;        /* fp32 */
     void *dst;              /* bf16 */
@@ -342,6 +344,13 @@ typedef struct MsCastDesc {
     int32_t inner, taps;
 } MsCastDesc;
 int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream);
+
+/* ---- dense 3x3 convolution of the conv branch (`nn.Conv2d(dim/2, dim/2, 3, padding=1)`, MedMamba.py:518-523) ---------------------
+ * stride 1, padding 1, groups 1, no bias; x (batch, H, W, Ci), y (batch, H, W, Co) bf16 channels_last memory; w bf16 in
+ * (Co, 3, 3, Ci) memory order (= a channels_last copy of the (Co, Ci, 3, 3) weight, what ms_cast_bf16_multi writes); fp32
+ * accumulation on the matrix cores.  Ci, Co multiples of 16.  The input gradient is the same call on dy with the flipped,
+ * transposed weight w'[ci][8 - tap][co]. */
+int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream);
 
 /* Diagnostic: force the workgroup tile of ms_gemm_bf16 (rows 64 / 128, columns 64 / 128 / 192; 0 = the built-in heuristic). */
 int ms_debug_gemm_tile(int block_rows, int block_cols);

@@ -267,9 +267,14 @@ class _ConvShadow(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, stride, padding, dilation):
         wb = shadow.bf16(weight, conv=True)
-        y = torch.ops.aten.convolution(x, wb, None, stride, padding, dilation, False, [0, 0], 1)
+        ctx.direct = _conv3x3_direct_ok(x, weight, stride, padding, dilation)
+        if ctx.direct:
+            y = _conv3x3_direct(x, wb)                    # ms_conv3x3_nhwc_bf16: csrc/conv3x3.hip
+        else:
+            y = torch.ops.aten.convolution(x, wb, None, stride, padding, dilation, False, [0, 0], 1)
         ctx.save_for_backward(x, wb)
         ctx.geom = (stride, padding, dilation)
+        ctx.weight_ref = weight
         return y
 
     @staticmethod
@@ -280,11 +285,41 @@ class _ConvShadow(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
+        need_dx = ctx.needs_input_grad[0]
+        dx_direct = None
+        if ctx.direct and need_dx:
+            # dx = conv3x3(dy, w') with the flipped / transposed weight copy (same kernel as the forward)
+            dx_direct = _conv3x3_direct(dy, shadow.bf16(ctx.weight_ref, conv="flip", in_backward=True))
+            need_dx = False
         dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, wb, None, stride, padding, dilation, False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+                                                        [need_dx, ctx.needs_input_grad[1], False])
+        if dx_direct is not None:
+            dx = dx_direct
         if dw is not None:
             dw = dw.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         return dx, dw, None, None, None
+
+
+_CONV_DIRECT = __import__("os").environ.get("MEDSCAN_CONV3X3", "1") == "1"
+_CONV_DIRECT_MIN_PIXELS = int(__import__("os").environ.get("MEDSCAN_CONV3X3_MIN_PIXELS", "196"))       # per image: 7x7 maps stay on MIOpen
+
+
+def _conv3x3_direct_ok(x, weight, stride, padding, dilation):
+    return (_CONV_DIRECT and x.is_cuda and x.dtype == torch.bfloat16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and list(stride) == [1, 1] and list(padding) == [1, 1] and list(dilation) == [1, 1]
+            and weight.shape[0] % 16 == 0 and weight.shape[1] % 16 == 0 and x.shape[2] * x.shape[3] >= _CONV_DIRECT_MIN_PIXELS
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _conv3x3_direct(x, w_nhwc):
+    """3x3 / stride 1 / padding 1 convolution of a bf16 channels_last activation with a bf16 weight in (Co, 3, 3, Ci) memory."""
+    B, Ci, H, W = x.shape
+    Co = w_nhwc.numel() // (9 * Ci)
+    y = torch.empty((B, Co, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().ms_conv3x3_nhwc_bf16(x.data_ptr(), w_nhwc.data_ptr(), y.data_ptr(), B, H, W, Ci, Co, _stream(x)),
+                   "ms_conv3x3_nhwc_bf16")
+    return y
 
 
 def _conv2d(conv, x):

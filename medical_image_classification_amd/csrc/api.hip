@@ -39,6 +39,7 @@ int block_tail_bwd_dispatch(const float *dout, const float *scale, const void *l
 int block_head_bwd_dispatch(const float *dout, const void *dl, int dl_is_bf16, const void *dr, int dr_is_bf16, float *dinp,
                             int64_t npix, int C, hipStream_t s);
 void gemm_debug_tile(int bm, int bn);
+int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, hipStream_t s);
 int cast_bf16_multi_dispatch(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, hipStream_t s);
 int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
                     int out_bf16, int64_t npix, int D, hipStream_t s);
@@ -71,6 +72,10 @@ int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda,
                           void *C, int c_mode, int64_t ldc, int M, int N, int K, const float *bias, int relu, void *stream) {
     return ms::gemm_bf16_dispatch(A, a_is_f32, a_trans, lda, B, b_is_f32, b_trans, ldb, C, c_mode, ldc, M, N, K, 1, bias, relu,
                                   (hipStream_t)stream);
+}
+
+int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream) {
+    return ms::conv3x3_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, (hipStream_t)stream);
 }
 
 int ms_debug_gemm_tile(int bm, int bn) { ms::gemm_debug_tile(bm, bn); return MS_OK; }

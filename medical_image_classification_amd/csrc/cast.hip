@@ -17,9 +17,23 @@ cast_bf16_multi_kernel(const MsCastDesc *__restrict__ desc) {
     const float *__restrict__ src = static_cast<const float *>(d.src);
     unsigned short *__restrict__ dst = static_cast<unsigned short *>(d.dst);
     const int64_t stride = (int64_t)gridDim.x * 256;
-    if (d.taps <= 1) {
+    if (d.taps >= 0 && d.taps <= 1) {
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < d.n; e += stride)
             dst[e] = __builtin_bit_cast(unsigned short, (__bf16)src[e]);
+        return;
+    }
+    if (d.taps < 0) {
+        // the weight of the INPUT-GRADIENT convolution: dst[(i * taps + (taps - 1 - k)) * outer + o] = src[(o * inner + i) * taps + k]
+        // (taps spatially flipped, in / out channels swapped), outer = n / (inner * taps)
+        const int taps = -d.taps, inner = d.inner;
+        const int64_t outer = d.n / ((int64_t)inner * taps);
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < d.n; e += stride) {
+            const int64_t ik = e / outer;                 // i * taps + k'
+            const int64_t o = e - ik * outer;
+            const int64_t i = ik / taps;
+            const int k = taps - 1 - (int)(ik - i * taps);
+            dst[e] = __builtin_bit_cast(unsigned short, (__bf16)src[(o * inner + i) * taps + k]);
+        }
         return;
     }
     // iterate in DESTINATION order (coalesced 2-byte stores; the strided 4-byte reads hit the same lines `taps` times in a row)

@@ -32,8 +32,9 @@ class _Shadow:
         self.t, self.version, self.ptr, self.conv, self.epoch, self.owner = t, -1, 0, conv, -1, owner
 
 
-_BY_ID = {}                       # id(parameter) -> _Shadow (entry removed when the parameter dies: nothing is stored ON the parameter,
-                                  # so pickling / deepcopy of a model never sees the cache)
+_BY_ID = {}                       # (id(parameter), kind) -> _Shadow (entries removed when the parameter dies: nothing is stored ON the
+                                  # parameter, so pickling / deepcopy of a model never sees the cache).  kind: False = plain copy,
+                                  # True = convolution weight in channels_last order, "flip" = the input-gradient convolution's weight
 
 
 class _Registry:
@@ -74,56 +75,79 @@ def _stale(p, sh, epoch):
     return sh.version != p._version or sh.ptr != p.data_ptr() or sh.epoch != epoch
 
 
-def _refresh(reg, device):
+def _refresh(reg, device, only=None):
+    """Refresh every stale copy of `device` in one launch -- or just `only` = (p, shadow) (a request from inside a backward pass)."""
     live, todo, seen = [], [], set()
-    for pid in reg.params:
-        sh = _BY_ID.get(pid)
-        p = sh.owner() if sh is not None else None
-        if p is None or pid in seen:                # dead, or an id the interpreter has recycled for a newer parameter
-            continue
-        seen.add(pid)
-        live.append(pid)
-        if p.is_cuda and p.device == device and sh.t.device == device and _stale(p, sh, reg.epoch):
-            todo.append((p, sh))
-    reg.params = live
+    if only is not None:
+        todo = [only]
+    else:
+        for pid in reg.params:
+            sh = _BY_ID.get(pid)
+            p = sh.owner() if sh is not None else None
+            if p is None or pid in seen:                # dead, or an id the interpreter has recycled for a newer parameter
+                continue
+            seen.add(pid)
+            live.append(pid)
+            if p.is_cuda and p.device == device and sh.t.device == device and _stale(p, sh, reg.epoch):
+                todo.append((p, sh))
+        reg.params = live
     if not todo:
         return
     # the cached descriptor table is valid only for EXACTLY these tensors: pointers alone are not enough -- the caching allocator
     # hands a freed parameter's address to the next model, whose tensor of another size would then be cast with the old extent
-    key = tuple((p.data_ptr(), sh.t.data_ptr(), p.numel(), tuple(p.shape) if sh.conv else 0) for p, sh in todo)
-    if reg.table is None or reg.table[0] != key:
+    key = tuple((p.data_ptr(), sh.t.data_ptr(), p.numel(), (tuple(p.shape), sh.conv) if sh.conv else 0) for p, sh in todo)
+    if only is not None or reg.table is None or reg.table[0] != key:
         arr = (MsCastDesc * len(todo))()
         biggest = 1
         for i, (p, sh) in enumerate(todo):
             taps = p.shape[2] * p.shape[3] if (sh.conv and p.dim() == 4) else 1
             arr[i].src, arr[i].dst, arr[i].n = p.data_ptr(), sh.t.data_ptr(), p.numel()
-            arr[i].inner, arr[i].taps = (p.shape[1] if taps > 1 else 1), taps
+            if sh.conv == "flip":
+                arr[i].inner, arr[i].taps = p.shape[1], -taps
+            else:
+                arr[i].inner, arr[i].taps = (p.shape[1] if taps > 1 else 1), taps
             biggest = max(biggest, p.numel())
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         blocks = max(1, min(64, (biggest + 2047) // 2048))
-        reg.table = (key, host.to(device), len(todo), blocks)
-    _, tab, n, blocks = reg.table
+        table = (key, host.to(device), len(todo), blocks)
+        if only is None:
+            reg.table = table                      # (a one-off table is not worth caching over the whole-model one)
+    else:
+        table = reg.table
+    _, tab, n, blocks = table
     with _lib.on_device(device):
         _lib.check(_lib.lib().ms_cast_bf16_multi(tab.data_ptr(), n, blocks, _lib.current_stream_ptr(device)), "ms_cast_bf16_multi")
     for p, sh in todo:
         sh.version, sh.ptr, sh.epoch = p._version, p.data_ptr(), reg.epoch
 
 
-def bf16(p, conv=False):
+def bf16(p, conv=False, in_backward=False):
     """bf16 copy of the fp32 CUDA tensor `p` (a Parameter).  conv=True: `p` is a (O, I, kh, kw) convolution weight and the copy has
-    channels_last strides (what MIOpen's NHWC kernels read).  No autograd history."""
+    channels_last strides (what the NHWC convolution kernels read); conv="flip": the weight of the INPUT-GRADIENT convolution,
+    (I, kh, kw, O) memory with the taps flipped.  No autograd history.
+    in_backward=True (a request from a Function's backward): the invalidations that the running backward pass has already issued
+    for the NEXT forward are ignored -- the weights have not changed yet -- so a copy refreshed during this step's forward is
+    served as is (otherwise every such request would refresh the whole model again)."""
     if not (_ENABLED and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
         t = p.detach().to(torch.bfloat16)
+        if conv == "flip":
+            return t.flip(2, 3).permute(1, 2, 3, 0).contiguous()
         return t.contiguous(memory_format=torch.channels_last) if (conv and p.dim() == 4) else t
     reg = _registry(p.device.index)
-    pid = id(p)
+    pid = (id(p), conv)
     sh = _BY_ID.get(pid)
-    if sh is None or sh.owner() is not p or sh.conv != conv or sh.t.shape != p.shape or sh.t.device != p.device:
-        fmt = torch.channels_last if (conv and p.dim() == 4) else torch.contiguous_format
-        if sh is None or sh.owner() is not p:
-            reg.params.append(pid)
-        sh = _BY_ID[pid] = _Shadow(torch.empty(p.shape, device=p.device, dtype=torch.bfloat16, memory_format=fmt), conv,
-                                   weakref.ref(p, lambda _r, pid=pid: _BY_ID.pop(pid, None)))
-    if _stale(p, sh, reg.epoch):
+    if sh is None or sh.owner() is not p or sh.t.numel() != p.numel() or sh.t.device != p.device:
+        if conv == "flip":             # (Ci, kh, kw, Co) memory: the weight of the input-gradient convolution
+            t = torch.empty((p.shape[1], p.shape[2], p.shape[3], p.shape[0]), device=p.device, dtype=torch.bfloat16)
+        else:
+            fmt = torch.channels_last if (conv and p.dim() == 4) else torch.contiguous_format
+            t = torch.empty(p.shape, device=p.device, dtype=torch.bfloat16, memory_format=fmt)
+        reg.params.append(pid)
+        sh = _BY_ID[pid] = _Shadow(t, conv, weakref.ref(p, lambda _r, pid=pid: _BY_ID.pop(pid, None)))
+    if in_backward:
+        if sh.version != p._version or sh.ptr != p.data_ptr() or sh.epoch < 0:
+            _refresh(reg, p.device, only=(p, sh))
+            sh.epoch = reg.epoch - 1               # current for THIS backward, still due for the next forward's refresh
+    elif _stale(p, sh, reg.epoch):
         _refresh(reg, p.device)
     return sh.t

@@ -1,0 +1,28 @@
+"""ms_conv3x3_nhwc_bf16 vs MIOpen (torch conv2d, channels_last bf16) at the conv-branch shapes of MedMamba-T bs 64: correctness and
+cold-cache time (a 1 GiB fill between calls)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from medical_image_classification_amd import _lib
+dev = torch.device("cuda:0"); lib = _lib.lib()
+flush = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+def cold(fn, n=6):
+    ts = []
+    for _ in range(n):
+        flush.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort(); return ts[len(ts) // 2]
+bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+for C, Hh in [(48, 56), (96, 28), (192, 14), (384, 7)]:
+    x = torch.randn(bs, C, Hh, Hh, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, C, 3, 3, device=dev) * (9 * C) ** -0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.empty_like(x)
+    st = _lib.current_stream_ptr(dev)
+    run = lambda: _lib.check(lib.ms_conv3x3_nhwc_bf16(x.data_ptr(), w.data_ptr(), y.data_ptr(), bs, Hh, Hh, C, C, st), "conv")
+    run(); torch.cuda.synchronize()
+    ref = F.conv2d(x.float(), w.float(), padding=1)
+    err = float((y.float() - ref).abs().max() / ref.abs().max())
+    t_ms = cold(run); t_mi = cold(lambda: F.conv2d(x, w, padding=1))
+    print(f"C={C:4d} {Hh}x{Hh}: ms {t_ms:6.1f} us  MIOpen {t_mi:6.1f} us   max rel err {err:.2e}", flush=True)
