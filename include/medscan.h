@@ -351,6 +351,12 @@ int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_ten
  * accumulation on the matrix cores.  Ci, Co multiples of 16.  The input gradient is the same call on dy with the flipped,
  * transposed weight w'[ci][8 - tap][co]. */
 int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream);
+/* Its weight gradient: dW (Co, Ci, 3, 3) fp32 contiguous is WRITTEN = sum over pixels of dy[p, co] * x[p + tap, ci] (x, dy bf16
+ * channels_last memory; Ci, Co multiples of 8).  `scratch`: ms_conv3x3_wgrad_scratch_floats(..) floats of workspace (the persistent
+ * workgroups' partial blocks, summed by a second kernel -- no atomics, no zero-fill, no cast passes). */
+int ms_conv3x3_wgrad(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W, int Ci,
+                     int Co, void *stream);
+int64_t ms_conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
 
 /* Diagnostic: force the workgroup tile of ms_gemm_bf16 (rows 64 / 128, columns 64 / 128 / 192; 0 = the built-in heuristic). */
 int ms_debug_gemm_tile(int block_rows, int block_cols);

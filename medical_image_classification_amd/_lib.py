@@ -57,7 +57,7 @@ EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks",
            "ms_dwconv3x3_silu_nhwc_bwd", "ms_dwconv3x3_silu_nhwc_bwd_scratch_floats", "ms_ln_gate_fwd", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_fwd_act", "ms_dtproj_bwd", "ms_dtproj_bwd_scratch_floats", "ms_bn_relu_nhwc_fwd",
            "ms_bn_relu_nhwc_bwd", "ms_bn_scratch_floats", "ms_ssd_chunk_carry", "ms_rms_gate_fwd", "ms_rms_gate_bwd", "ms_gemm_bf16", "ms_gemm_bf16_bias_act",
-           "ms_cast_bf16_multi", "ms_block_tail_bwd_relu", "ms_block_head_bwd", "ms_debug_gemm_tile", "ms_conv3x3_nhwc_bf16", "ms_spin", "ms_abi_version", "ms_status_string")
+           "ms_cast_bf16_multi", "ms_block_tail_bwd_relu", "ms_block_head_bwd", "ms_debug_gemm_tile", "ms_conv3x3_nhwc_bf16", "ms_conv3x3_wgrad", "ms_conv3x3_wgrad_scratch_floats", "ms_spin", "ms_abi_version", "ms_status_string")
 ABI_VERSION = 6
 
 _lib = None
@@ -128,6 +128,8 @@ def lib():
     h.ms_gemm_bf16.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_vp]
     h.ms_debug_gemm_tile.argtypes = [c_int, c_int]
     h.ms_conv3x3_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]
+    h.ms_conv3x3_wgrad.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]
+    h.ms_conv3x3_wgrad_scratch_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
     h.ms_spin.argtypes = [ctypes.c_longlong, c_vp]
     h.ms_status_string.restype = ctypes.c_char_p
     h.ms_status_string.argtypes = [ctypes.c_int]
@@ -135,6 +137,7 @@ def lib():
         getattr(h, name).restype = ctypes.c_int
     h.ms_dwconv3x3_silu_nhwc_bwd_scratch_floats.restype = c_i64
     h.ms_dtproj_bwd_scratch_floats.restype = c_i64
+    h.ms_conv3x3_wgrad_scratch_floats.restype = c_i64
     if h.ms_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != {ABI_VERSION} (stale build?)")
     _lib = h

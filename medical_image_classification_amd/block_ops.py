@@ -291,10 +291,19 @@ class _ConvShadow(torch.autograd.Function):
             # dx = conv3x3(dy, w') with the flipped / transposed weight copy (same kernel as the forward)
             dx_direct = _conv3x3_direct(dy, shadow.bf16(ctx.weight_ref, conv="flip", in_backward=True))
             need_dx = False
-        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, wb, None, stride, padding, dilation, False, [0, 0], 1,
-                                                        [need_dx, ctx.needs_input_grad[1], False])
+        need_dw = ctx.needs_input_grad[1]
+        dw_direct = None
+        if ctx.direct and need_dw and _CONV_WGRAD:
+            dw_direct = _conv3x3_wgrad(x, dy, wb.shape)  # fp32 (Co, Ci, 3, 3), written: no zero-fill, no cast pass
+            need_dw = False
+        dx = dw = None
+        if need_dx or need_dw:
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, wb, None, stride, padding, dilation, False, [0, 0], 1,
+                                                            [need_dx, need_dw, False])
         if dx_direct is not None:
             dx = dx_direct
+        if dw_direct is not None:
+            return dx, dw_direct, None, None, None
         if dw is not None:
             dw = dw.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         return dx, dw, None, None, None
@@ -309,6 +318,26 @@ def _conv3x3_direct_ok(x, weight, stride, padding, dilation):
             and list(stride) == [1, 1] and list(padding) == [1, 1] and list(dilation) == [1, 1]
             and weight.shape[0] % 16 == 0 and weight.shape[1] % 16 == 0 and x.shape[2] * x.shape[3] >= _CONV_DIRECT_MIN_PIXELS
             and x.is_contiguous(memory_format=torch.channels_last))
+
+
+# the hand-written weight-gradient kernel is correct and tested but NOT faster in situ yet: its main kernel takes 35 us where MIOpen's
+# takes 39-49 us, but summing the 512 persistent workgroups' partial blocks costs another 34 us (MIOpen's zero-fill + cast helpers:
+# ~20 us); MedMamba-T step 20.76 ms with it, 20.54 ms without.  Off by default.
+_CONV_WGRAD = __import__("os").environ.get("MEDSCAN_CONV3X3_WGRAD", "0") == "1"
+
+
+def _conv3x3_wgrad(x, dy, wshape):
+    """Weight gradient of the 3x3 / stride 1 / padding 1 convolution from bf16 channels_last x and dy: fp32 (Co, Ci, 3, 3)."""
+    B, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    lib = _lib.lib()
+    ns = lib.ms_conv3x3_wgrad_scratch_floats(B, H, W, Ci, Co)
+    scratch = torch.empty(ns, device=x.device, dtype=torch.float32)
+    dw = torch.empty((Co, Ci, 3, 3), device=x.device, dtype=torch.float32)
+    with _lib.on_device(x.device):
+        _lib.check(lib.ms_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), ns, B, H, W, Ci, Co, _stream(x)),
+                   "ms_conv3x3_wgrad")
+    return dw
 
 
 def _conv3x3_direct(x, w_nhwc):

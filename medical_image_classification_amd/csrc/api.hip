@@ -40,6 +40,9 @@ int block_head_bwd_dispatch(const float *dout, const void *dl, int dl_is_bf16, c
                             int64_t npix, int C, hipStream_t s);
 void gemm_debug_tile(int bm, int bn);
 int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, hipStream_t s);
+int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W,
+                           int Ci, int Co, hipStream_t s);
+int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
 int cast_bf16_multi_dispatch(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, hipStream_t s);
 int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
                     int out_bf16, int64_t npix, int D, hipStream_t s);
@@ -76,6 +79,15 @@ int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda,
 
 int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream) {
     return ms::conv3x3_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, (hipStream_t)stream);
+}
+
+int ms_conv3x3_wgrad(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W, int Ci,
+                     int Co, void *stream) {
+    return ms::conv3x3_wgrad_dispatch(x, dy, dW, scratch, scratch_floats, batch, H, W, Ci, Co, (hipStream_t)stream);
+}
+
+int64_t ms_conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co) {
+    return ms::conv3x3_wgrad_scratch_floats(batch, H, W, Ci, Co);
 }
 
 int ms_debug_gemm_tile(int bm, int bn) { ms::gemm_debug_tile(bm, bn); return MS_OK; }

@@ -116,4 +116,149 @@ int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int 
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
+
+// ---- weight gradient -----------------------------------------------------------------------------------------------------
+//   dW[co][tap][ci] = sum over (image, h, w) of dy[h, w, co] * x[h + dy - 1, w + dx - 1, ci]
+// The reduction axis of the MFMA is the PIXEL axis: one k-step = the 16 pixels of one image row of the 8 x 16 tile.  Both operands
+// sit in LDS as they are in memory, [pixel][channel], and are read with ds_read_b64_tr_b16 (the transposing LDS read: a 16-lane
+// group fetches 4 pixels x 16 channels, every lane receives the 4 pixel values of ITS channel) -- no transposed copies.
+//   workgroup = a block of 48 output x 48 input channels, persistent over pixel tiles; the 3 x 27 products (3 co tiles x 9 taps x
+//   3 ci tiles) are dealt to the 4 waves by product column (27 = 7 + 7 + 7 + 6 columns, every wave all 3 co tiles): per k-step a
+//   wave reads 3 + 7 fragments for 21 MFMAs and keeps 21 accumulator tiles (84 VGPRs).
+//   The workgroup's partial block goes to a workspace row; ms_conv3x3_wgrad sums the rows into the fp32 (Co, Ci, 3, 3) gradient.
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int kGC = 48;                          // channels per block (both sides)
+constexpr int kGP = kGC + 8;                     // LDS pixel pitch (bf16)
+}
+
+__device__ __forceinline__ bf16x4 tr_frag(const unsigned short *s_pix0, int pitch, int lane) {
+    // fragment of 16 channels (starting at s_pix0's channel) x 16 pixels (rows of the [pixel][channel] image starting at s_pix0):
+    // lane (fr = channel, fq = pixel group) receives pixels 4 fq .. 4 fq + 3 of channel fr
+    const int fr = lane & 15, fq = lane >> 4;
+    typedef bf16x4 __attribute__((address_space(3))) *lds_p;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(s_pix0 + (4 * fq + (fr >> 2)) * pitch + 4 * (fr & 3)));
+}
+
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, float *__restrict__ part,
+                     int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img, int n_tiles, int nci) {
+    __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kGP];      // x halo tile, 48 input channels
+    __shared__ __attribute__((aligned(16))) unsigned short sG[kTH * kTW * kGP];      // dy tile, 48 output channels
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cob = blockIdx.y / nci, cib = blockIdx.y % nci;
+    const int co0 = cob * kGC, ci0 = cib * kGC;
+    // this wave's product columns: col = tap * 3 + ci tile, col % 4 == wv
+    constexpr int kMaxCols = 7;
+    f32x4 acc[3][kMaxCols];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < kMaxCols; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, tt = tile - img * tiles_per_img;
+        const int h0 = (tt / tiles_w) * kTH, w0 = (tt % tiles_w) * kTW;
+        __syncthreads();
+        for (int idx = tid; idx < kHH * kHW * (kGC / 8); idx += 256) {
+            const int pix = idx / (kGC / 8), pc = idx - pix * (kGC / 8);
+            const int hh = h0 - 1 + pix / kHW, ww = w0 - 1 + pix % kHW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W && ci0 + pc * 8 < Ci)
+                v = *reinterpret_cast<const uint4 *>(x + (((int64_t)img * H + hh) * W + ww) * Ci + ci0 + pc * 8);
+            *reinterpret_cast<uint4 *>(sX + pix * kGP + pc * 8) = v;
+        }
+        for (int idx = tid; idx < kTH * kTW * (kGC / 8); idx += 256) {
+            const int pix = idx / (kGC / 8), pc = idx - pix * (kGC / 8);
+            const int hh = h0 + pix / kTW, ww = w0 + pix % kTW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (hh < H && ww < W && co0 + pc * 8 < Co)
+                v = *reinterpret_cast<const uint4 *>(dy + (((int64_t)img * H + hh) * W + ww) * Co + co0 + pc * 8);
+            *reinterpret_cast<uint4 *>(sG + pix * kGP + pc * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int r = 0; r < kTH; ++r) {
+            bf16x4 ga[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ga[a] = tr_frag(sG + (r * kTW) * kGP + a * 16, kGP, lane);
+#pragma unroll
+            for (int j = 0; j < kMaxCols; ++j) {
+                const int col = wv + 4 * j;                       // compile-time j, wave-uniform col
+                if (col < 27) {
+                    const int tap = col / 3, ct = col - tap * 3;
+                    const int dyy = tap / 3, dxx = tap - dyy * 3;
+                    const bf16x4 xb = tr_frag(sX + ((r + dyy) * kHW + dxx) * kGP + ct * 16, kGP, lane);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[a], xb, acc[a][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[co][ci]: lane (ci = fr) holds co = 4 fq + r.  Partial block layout: [co (48)][tap (9)][ci (48)] fp32 per (blockIdx.x, blockIdx.y)
+    const int fr = lane & 15, fq = lane >> 4;
+    float *pb = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (kGC * 9 * kGC);
+#pragma unroll
+    for (int j = 0; j < kMaxCols; ++j) {
+        const int col = wv + 4 * j;
+        if (col < 27) {
+            const int tap = col / 3, ct = col - tap * 3;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    pb[((a * 16 + 4 * fq + rr) * 9 + tap) * kGC + ct * 16 + fr] = acc[a][j][rr];
+        }
+    }
+}
+
+// dW (Co, Ci, 3, 3) fp32 contiguous = sum of the workers' partial blocks [worker][co block][ci block][48][9][48]
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_finalize_kernel(const float *__restrict__ part, float *__restrict__ dW, int Ci, int Co, int nci, int nblk, int nworkers) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;            // element of dW in (co, ci, tap) order
+    if (e >= (int64_t)Co * Ci * 9) return;
+    const int tap = (int)(e % 9);
+    const int64_t cc = e / 9;
+    const int ci = (int)(cc % Ci), co = (int)(cc / Ci);
+    const int blk = (co / kGC) * nci + ci / kGC;
+    const int64_t off = (((int64_t)(co % kGC) * 9 + tap) * kGC + ci % kGC) + (int64_t)blk * (kGC * 9 * kGC);
+    const int64_t wstride = (int64_t)nblk * (kGC * 9 * kGC);
+    float a0 = 0.0f, a1 = 0.0f;
+    int wk = 0;
+    for (; wk + 2 <= nworkers; wk += 2) { a0 += part[off + wk * wstride]; a1 += part[off + (wk + 1) * wstride]; }
+    if (wk < nworkers) a0 += part[off + wk * wstride];
+    dW[e] = a0 + a1;
+}
+
+static int wgrad_workers(int n_tiles, int nblk) {
+    int wk = (512 + nblk - 1) / nblk;                       // about two workgroups per CU in total (256: main 55 + finalize 18 us; 512: 35 + 34)
+    if (wk > n_tiles) wk = n_tiles;
+    return wk < 1 ? 1 : wk;
+}
+
+int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co) {
+    if (batch <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+    const int n_tiles = batch * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+    const int nblk = ((Co + kGC - 1) / kGC) * ((Ci + kGC - 1) / kGC);
+    return (int64_t)wgrad_workers(n_tiles, nblk) * nblk * (kGC * 9 * kGC);
+}
+
+int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W,
+                           int Ci, int Co, hipStream_t s) {
+    if (!x || !dy || !dW || !scratch) return MS_ERR_NULL;
+    if (batch <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 8 != 0 || Co % 8 != 0) return MS_ERR_SHAPE;
+    if (scratch_floats < conv3x3_wgrad_scratch_floats(batch, H, W, Ci, Co)) return MS_ERR_SHAPE;
+    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH;
+    const int tiles_per_img = tiles_w * tiles_h, n_tiles = batch * tiles_per_img;
+    const int nco = (Co + kGC - 1) / kGC, nci = (Ci + kGC - 1) / kGC, nblk = nco * nci;
+    const int wk = wgrad_workers(n_tiles, nblk);
+    using bf = unsigned short;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)wk, (unsigned)nblk), dim3(256), 0, s, (const bf *)x, (const bf *)dy, scratch, H, W,
+                       Ci, Co, tiles_w, tiles_per_img, n_tiles, nci);
+    const int64_t n = (int64_t)Co * Ci * 9;
+    hipLaunchKernelGGL(conv3x3_wgrad_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dW, Ci, Co, nci, nblk, wk);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
 }  // namespace ms

@@ -111,6 +111,13 @@ def test_direct_conv3x3_forward_and_input_gradient_vs_fp32(cfg):
     for got, want, name in ((y, yr, "y"), (dx, dxr, "dx")):
         np.testing.assert_allclose(got.float().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-2, atol=6e-3 * float(want.abs().max()),
                                    err_msg=name)
+    # weight gradient: fp32 accumulation of bf16 products, written (no zero-fill), (Co, Ci, 3, 3) contiguous
+    from medical_image_classification_amd.block_ops import _conv3x3_wgrad
+    dw = _conv3x3_wgrad(x, g, w.shape)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_()
+    (dwr,) = torch.autograd.grad(F.conv2d(x.float(), wr, padding=1), wr, g.float())
+    assert dw.dtype == torch.float32 and dw.shape == w.shape and dw.is_contiguous()
+    np.testing.assert_allclose(dw.cpu().numpy(), dwr.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(dwr.abs().max()), err_msg="dW")
 
 
 @pytest.mark.parametrize("cfg", [(2, 48, 56, 56), (3, 96, 9, 7), (64, 384, 7, 7)])
