@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 6
+#define MEDSCAN_ABI_VERSION 7
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -205,10 +205,16 @@ int64_t ms_dwconv3x3_silu_nhwc_bwd_scratch_floats(int batch, int C, int H, int W
  *   out  = (LN(((y0+y2)+y1)+y3) * gamma + beta) * silu(z)      (npix, D) contiguous, fp32 or bf16 (out_is_bf16)
  * bwd: dout (npix, D) fp32|bf16 -> dy (npix, D) fp32 (the dout of all four scan directions), dz (npix, D) in z's
  *      dtype, and ACCUMULATES dgamma, dbeta (D).  y and the LN statistics are recomputed from y4.
+ * ms_ln_gate_fwd_keep additionally stores the merged sum ((y0+y2)+y1)+y3 in ysum (npix, D) fp32; the backward accepts it in
+ * place of the four slabs: dir_stride == 0 means `y4` IS that sum (4 B instead of 16 B read per element, and the four slabs
+ * need not outlive the forward).
  */
 int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
                    const float *gamma, const float *beta, float eps, void *out, int out_is_bf16,
                    int64_t npix, int D, void *stream);
+int ms_ln_gate_fwd_keep(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                        const float *gamma, const float *beta, float eps, void *out, int out_is_bf16, float *ysum,
+                        int64_t npix, int D, void *stream);
 int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
                    const float *gamma, const float *beta, float eps, const void *dout, int dout_is_bf16,
                    float *dy, void *dz, int64_t dz_pixel_stride, float *dgamma, float *dbeta, int64_t npix, int D,

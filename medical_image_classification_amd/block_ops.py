@@ -320,10 +320,10 @@ def _conv3x3_direct_ok(x, weight, stride, padding, dilation):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-# the hand-written weight-gradient kernel is correct and tested but NOT faster in situ yet: its main kernel takes 35 us where MIOpen's
-# takes 39-49 us, but summing the 512 persistent workgroups' partial blocks costs another 34 us (MIOpen's zero-fill + cast helpers:
-# ~20 us); MedMamba-T step 20.76 ms with it, 20.54 ms without.  Off by default.
-_CONV_WGRAD = __import__("os").environ.get("MEDSCAN_CONV3X3_WGRAD", "0") == "1"
+# the hand-written weight-gradient kernel (ms_conv3x3_wgrad: persistent MFMA workgroups + a coalesced partial-block sum) replaces
+# MIOpen's bf16 weight-gradient kernels and the zero-fill / cast helper launches around them: cold 52-59 us per call against 49-62 us,
+# MedMamba-T step 20.28 -> 20.14 ms and ~100 fewer launches per step.  MEDSCAN_CONV3X3_WGRAD=0 goes back to MIOpen.
+_CONV_WGRAD = __import__("os").environ.get("MEDSCAN_CONV3X3_WGRAD", "1") == "1"
 
 
 def _conv3x3_wgrad(x, dy, wshape):

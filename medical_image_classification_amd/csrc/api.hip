@@ -28,7 +28,7 @@ int dwconv_nhwc_bwd_dispatch(const void *x, int x_is_bf16, const float *w, const
                              int64_t dir_stride, const float *dy_extra, void *dx, int dx_bf16, int64_t dxps, float *scratch,
                              float *dw, float *dbias, int batch, int C, int H, int W, int64_t xps, hipStream_t s);
 int ln_gate_fwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
-                         const float *beta, float eps, void *out, int out_bf16, int64_t npix, int D, hipStream_t s);
+                         const float *beta, float eps, void *out, int out_bf16, float *ysum, int64_t npix, int D, hipStream_t s);
 int ln_gate_bwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
                          const float *beta, float eps, const void *dout, int dout_bf16, float *dy, void *dz, int64_t dzps,
                          float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
@@ -157,7 +157,15 @@ int ms_ln_gate_fwd(const float *y4, int64_t dir_stride, const void *z, int z_is_
                    const float *gamma, const float *beta, float eps, void *out, int out_is_bf16,
                    int64_t npix, int D, void *stream) {
     return ms::ln_gate_fwd_dispatch(y4, dir_stride, z, z_is_bf16, z_pixel_stride, gamma, beta, eps, out, out_is_bf16,
-                                    npix, D, (hipStream_t)stream);
+                                    nullptr, npix, D, (hipStream_t)stream);
+}
+
+int ms_ln_gate_fwd_keep(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,
+                        const float *gamma, const float *beta, float eps, void *out, int out_is_bf16, float *ysum,
+                        int64_t npix, int D, void *stream) {
+    if (!ysum) return MS_ERR_NULL;
+    return ms::ln_gate_fwd_dispatch(y4, dir_stride, z, z_is_bf16, z_pixel_stride, gamma, beta, eps, out, out_is_bf16,
+                                    ysum, npix, D, (hipStream_t)stream);
 }
 
 int ms_ln_gate_bwd(const float *y4, int64_t dir_stride, const void *z, int z_is_bf16, int64_t z_pixel_stride,

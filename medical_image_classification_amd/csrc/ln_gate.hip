@@ -32,7 +32,7 @@ template <int VPT, typename TZ, typename TO>
 __global__ void __launch_bounds__(256)
 ln_gate_fwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restrict__ z, int64_t zps,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                   TO *__restrict__ out, int D, int64_t npix) {
+                   TO *__restrict__ out, float *__restrict__ ysum, int D, int64_t npix) {
     const int lane = threadIdx.x & 63;
     const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= npix) return;
@@ -44,6 +44,7 @@ ln_gate_fwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
         const int c = lane + 64 * j;
         y[j] = c < D ? ((yp[c] + yp[2 * sk + c]) + yp[sk + c]) + yp[3 * sk + c] : 0.0f;
         s1 += y[j];
+        if (ysum && c < D) ysum[pix * D + c] = y[j];         // the merged sum, kept for the backward (4 B instead of 16 B per element there)
     }
     const float mean = wave_sum(s1) / (float)D;
     float s2 = 0.0f;
@@ -104,7 +105,8 @@ ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
 #pragma unroll
             for (int j = 0; j < VPT; ++j) {
                 const int c = lane + 64 * j;
-                y[q][j] = c < D ? ((yp[c] + yp[2 * sk + c]) + yp[sk + c]) + yp[3 * sk + c] : 0.0f;
+                // sk == 0: y4 IS the merged sum the forward kept (wave-uniform branch)
+                y[q][j] = c < D ? (sk ? ((yp[c] + yp[2 * sk + c]) + yp[sk + c]) + yp[3 * sk + c] : yp[c]) : 0.0f;
                 zz[q][j] = c < D ? ld(z + pix * zps + c) : 0.0f;
                 g[q][j] = c < D ? ld(dout + pix * D + c) : 0.0f;
                 s1[q] += y[q][j];
@@ -176,10 +178,10 @@ ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
 
 template <typename TZ, typename TO>
 static int launch_fwd(const float *y4, int64_t sk, const void *z, int64_t zps, const float *gamma, const float *beta,
-                      float eps, void *out, int D, int64_t npix, hipStream_t s) {
+                      float eps, void *out, float *ysum, int D, int64_t npix, hipStream_t s) {
     const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
     const int vpt = (D + 63) / 64;
-#define MS_L(V) hipLaunchKernelGGL((ln_gate_fwd_kernel<V, TZ, TO>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (TO *)out, D, npix)
+#define MS_L(V) hipLaunchKernelGGL((ln_gate_fwd_kernel<V, TZ, TO>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (TO *)out, ysum, D, npix)
     if (vpt <= 1) MS_L(1); else if (vpt <= 2) MS_L(2); else if (vpt <= 3) MS_L(3); else if (vpt <= 4) MS_L(4);
     else if (vpt <= 6) MS_L(6); else if (vpt <= 8) MS_L(8); else if (vpt <= 12) MS_L(12); else MS_L(16);
 #undef MS_L
@@ -187,14 +189,14 @@ static int launch_fwd(const float *y4, int64_t sk, const void *z, int64_t zps, c
 }
 
 int ln_gate_fwd_dispatch(const float *y4, int64_t sk, const void *z, int z_bf16, int64_t zps, const float *gamma,
-                         const float *beta, float eps, void *out, int out_bf16, int64_t npix, int D, hipStream_t s) {
+                         const float *beta, float eps, void *out, int out_bf16, float *ysum, int64_t npix, int D, hipStream_t s) {
     if (!y4 || !z || !gamma || !beta || !out) return MS_ERR_NULL;
     if (D <= 0 || D > 64 * kMaxVPT || npix < 0 || zps < D) return MS_ERR_SHAPE;
     if (npix == 0) return MS_OK;
-    if (z_bf16) return out_bf16 ? launch_fwd<unsigned short, unsigned short>(y4, sk, z, zps, gamma, beta, eps, out, D, npix, s)
-                                : launch_fwd<unsigned short, float>(y4, sk, z, zps, gamma, beta, eps, out, D, npix, s);
-    return out_bf16 ? launch_fwd<float, unsigned short>(y4, sk, z, zps, gamma, beta, eps, out, D, npix, s)
-                    : launch_fwd<float, float>(y4, sk, z, zps, gamma, beta, eps, out, D, npix, s);
+    if (z_bf16) return out_bf16 ? launch_fwd<unsigned short, unsigned short>(y4, sk, z, zps, gamma, beta, eps, out, ysum, D, npix, s)
+                                : launch_fwd<unsigned short, float>(y4, sk, z, zps, gamma, beta, eps, out, ysum, D, npix, s);
+    return out_bf16 ? launch_fwd<float, unsigned short>(y4, sk, z, zps, gamma, beta, eps, out, ysum, D, npix, s)
+                    : launch_fwd<float, float>(y4, sk, z, zps, gamma, beta, eps, out, ysum, D, npix, s);
 }
 
 template <typename TZ, typename TG>

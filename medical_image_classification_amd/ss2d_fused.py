@@ -378,10 +378,18 @@ class _SS2DInner(torch.autograd.Function):
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), dev,
                               lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream), B * 4 * D * L * N)
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
-            _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
-                                          beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), M, D, stream),
-                       "ms_ln_gate_fwd")
-        ctx.save_for_backward(xz, xc, xm if (mm_dtype is not None and not mfma) else None, wx, proj, delta, x_state, y4, cw, cb, wdt,
+            # training keeps the MERGED sum of the four direction slabs for the backward (ms_ln_gate_fwd_keep): the LayerNorm
+            # backward then reads 4 B instead of 16 B per element and the slabs are released here
+            ysum = torch.empty((B, L, D), device=dev, dtype=torch.float32) if any(ctx.needs_input_grad) else None
+            if ysum is None:
+                _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
+                                              beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), M, D, stream),
+                           "ms_ln_gate_fwd")
+            else:
+                _lib.check(lib.ms_ln_gate_fwd_keep(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
+                                                   beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), ysum.data_ptr(),
+                                                   M, D, stream), "ms_ln_gate_fwd_keep")
+        ctx.save_for_backward(xz, xc, xm if (mm_dtype is not None and not mfma) else None, wx, proj, delta, x_state, ysum, cw, cb, wdt,
                               A, Dv, bias, gamma, beta)
         ctx.geom = (N, R, float(eps))
         ctx.mfma, ctx.act = mfma, act
@@ -390,7 +398,7 @@ class _SS2DInner(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        xz, xc, xm, wx, proj, delta, x_state, y4, cw, cb, wdt, A, Dv, bias, gamma, beta = ctx.saved_tensors
+        xz, xc, xm, wx, proj, delta, x_state, ysum, cw, cb, wdt, A, Dv, bias, gamma, beta = ctx.saved_tensors
         N, R, eps = ctx.geom
         lib = _lib.lib()
         B, H, W, D2 = xz.shape
@@ -424,7 +432,7 @@ class _SS2DInner(torch.autograd.Function):
         Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
         stream = _lib.current_stream_ptr(dev)
         with _lib.on_device(dev):
-            _lib.check(lib.ms_ln_gate_bwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
+            _lib.check(lib.ms_ln_gate_bwd(ysum.data_ptr(), 0, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),      # dir_stride 0: the merged sum
                                           beta.data_ptr(), eps, dout.data_ptr(), int(dout.dtype == torch.bfloat16),
                                           dy.data_ptr(), dxz.data_ptr() + D * isz, D2, dgamma.data_ptr(), dbeta.data_ptr(),
                                           M, D, stream), "ms_ln_gate_bwd")

@@ -336,6 +336,22 @@ def test_ln_gate_kernels_vs_torch(cfg, bf16):
     sc = max(1.0, float(gr.grad.abs().max()))
     assert_close(dgam, gr.grad.numpy(), 1e-3, 1e-4 * sc, "dgamma")
     assert_close(dbet, br.grad.numpy(), 1e-3, 1e-4 * sc, "dbeta")
+    # ms_ln_gate_fwd_keep: same output, and the merged sum it keeps feeds the backward (dir_stride 0) with bit-identical results
+    out2 = torch.empty_like(out); ysum = torch.empty(npix, D, device=d)
+    _lib.check(lib.ms_ln_gate_fwd_keep(y4d.data_ptr(), npix * D, zptr, int(bf16), 2 * D, gamd.data_ptr(), betd.data_ptr(), 1e-5,
+                                       out2.data_ptr(), int(bf16), ysum.data_ptr(), npix, D, st), "fwd_keep")
+    assert torch.equal(out2, out)
+    assert torch.equal(ysum, ((y4d[0] + y4d[2]) + y4d[1]) + y4d[3])
+    dy2 = torch.empty_like(dy); dz2 = torch.empty_like(dz)
+    dgam2, dbet2 = torch.zeros(D, device=d), torch.zeros(D, device=d)
+    _lib.check(lib.ms_ln_gate_bwd(ysum.data_ptr(), 0, zptr, int(bf16), 2 * D, gamd.data_ptr(), betd.data_ptr(), 1e-5,
+                                  gd.data_ptr(), int(bf16), dy2.data_ptr(), dz2.data_ptr(), D, dgam2.data_ptr(),
+                                  dbet2.data_ptr(), npix, D, st), "bwd_merged")
+    assert torch.equal(dy2, dy) and torch.equal(dz2, dz)
+    assert_close(dgam2, dgam.cpu().numpy(), 1e-5, 1e-5 * sc, "dgamma (merged)")       # atomics: order of the block sums varies
+    assert_close(dbet2, dbet.cpu().numpy(), 1e-5, 1e-5 * sc, "dbeta (merged)")
+    assert lib.ms_ln_gate_fwd_keep(y4d.data_ptr(), npix * D, zptr, int(bf16), 2 * D, gamd.data_ptr(), betd.data_ptr(), 1e-5,
+                                   out2.data_ptr(), int(bf16), None, npix, D, st) != 0
 
 
 def test_medmamba_b_512_train_step_runs():

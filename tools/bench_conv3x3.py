@@ -26,3 +26,14 @@ for C, Hh in [(48, 56), (96, 28), (192, 14), (384, 7)]:
     err = float((y.float() - ref).abs().max() / ref.abs().max())
     t_ms = cold(run); t_mi = cold(lambda: F.conv2d(x, w, padding=1))
     print(f"C={C:4d} {Hh}x{Hh}: ms {t_ms:6.1f} us  MIOpen {t_mi:6.1f} us   max rel err {err:.2e}", flush=True)
+    # weight gradient: ms_conv3x3_wgrad (main + finalize) vs MIOpen's (incl. its helper launches)
+    if Hh * Hh >= 196:
+        dy = torch.randn_like(x)
+        ns = lib.ms_conv3x3_wgrad_scratch_floats(bs, Hh, Hh, C, C)
+        scratch = torch.empty(ns, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)
+        runw = lambda: _lib.check(lib.ms_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), ns, bs, Hh, Hh, C, C, st), "wgrad")
+        runw(); torch.cuda.synchronize()
+        refw = torch.ops.aten.convolution_backward(dy.float(), x.float(), w.float(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        errw = float((dw - refw).abs().max() / refw.abs().max())
+        miw = lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
+        print(f"        wgrad: ms {cold(runw):6.1f} us  MIOpen {cold(miw):6.1f} us   max rel err {errw:.2e}", flush=True)
