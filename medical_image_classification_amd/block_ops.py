@@ -310,7 +310,7 @@ class _ConvShadow(torch.autograd.Function):
 
 
 _CONV_DIRECT = __import__("os").environ.get("MEDSCAN_CONV3X3", "1") == "1"
-_CONV_DIRECT_MIN_PIXELS = int(__import__("os").environ.get("MEDSCAN_CONV3X3_MIN_PIXELS", "196"))       # per image: 7x7 maps stay on MIOpen
+_CONV_DIRECT_MIN_PIXELS = int(__import__("os").environ.get("MEDSCAN_CONV3X3_MIN_PIXELS", "49"))       # per image; 7x7 maps (stage 3) included since the pipelined kernel: 42 vs 53 us
 
 
 def _conv3x3_direct_ok(x, weight, stride, padding, dilation):

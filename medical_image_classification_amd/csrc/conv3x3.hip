@@ -23,9 +23,16 @@ constexpr int kXP = kKS + 8;                     // halo pixel pitch (bf16): 144
 constexpr int kWP = kKS + 8;                     // weight row pitch (bf16)
 }
 
-// NB = output-channel tiles of 16 per workgroup (3 or 6: 48 or 96 channels)
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// NB = output-channel tiles of 16 per workgroup (3: 48 channels).
+// Staging is software-pipelined through registers: ALL 16-byte loads of a channel slice (halo + weights: <= 10 per thread) are
+// issued back to back into registers, and the NEXT slice's loads are in flight while the current slice is multiplied.  (The
+// first version ran `load -> LDS store` loops with run-time trip counts: ten dependent global-load round trips per slice, which
+// -- not the MFMAs, not LDS -- were the kernel's time.)  Slices of 32 channels use v_mfma_f32_16x16x32_bf16 (one ds_read_b128 per
+// fragment), a 16-channel tail slice the K = 16 form.
 template <int NB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 49 KB of LDS: three workgroups per CU
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
                     int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img) {
     __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kXP];
@@ -43,39 +50,79 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
         for (int n = 0; n < NB; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const unsigned short *xi = x + (int64_t)img * H * W * Ci;
-    for (int k0 = 0; k0 < Ci; k0 += kKS) {
-        const int ks = min(kKS, Ci - k0);                       // channels in this slice (multiple of 16)
-        __syncthreads();                                        // the previous slice's fragments have been read
-        // halo tile: kHH x kHW pixels x ks channels, 16-byte pieces; out-of-image pixels are zero
-        const int pieces = ks / 8;
-        for (int idx = tid; idx < kHH * kHW * pieces; idx += 256) {
-            const int pix = idx / pieces, pc = idx - pix * pieces;
-            const int hh = h0 - 1 + pix / kHW, ww = w0 - 1 + pix % kHW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = *reinterpret_cast<const uint4 *>(xi + ((int64_t)hh * W + ww) * Ci + k0 + pc * 8);
-            *reinterpret_cast<uint4 *>(sX + pix * kXP + pc * 8) = v;
-        }
-        // weights of this channel slice: [tap][co (NB * 16)][ks]; w is (Co, 9, Ci)
-        for (int idx = tid; idx < 9 * NB * 16 * pieces; idx += 256) {
-            const int row = idx / pieces, pc = idx - row * pieces;       // row = tap * (NB*16) + col
-            const int tap = row / (NB * 16), col = row - tap * (NB * 16);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (co0 + col < Co) v = *reinterpret_cast<const uint4 *>(w + ((int64_t)(co0 + col) * 9 + tap) * Ci + k0 + pc * 8);
-            *reinterpret_cast<uint4 *>(sW + row * kWP + pc * 8) = v;
-        }
-        __syncthreads();
+    constexpr int kNX = (kHH * kHW * (kKS / 8) + 255) / 256;            // 16-byte pieces per thread: halo (3) ...
+    constexpr int kNW = (9 * NB * 16 * (kKS / 8) + 255) / 256;          // ... and weights (7 at NB = 3)
+    uint4 rx[kNX], rw[kNW];
+    // a slice holds 32 or 16 channels (Ci % 16 == 0): 4 or 2 pieces per pixel / weight row
+    auto fetch = [&](int k0) {
+        const int psh = (Ci - k0 >= kKS) ? 2 : 1, pm = (1 << psh) - 1;
+        const int nx = (kHH * kHW) << psh, nw = (9 * NB * 16) << psh;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            for (int kk = 0; kk < ks; kk += 16) {
+        for (int i = 0; i < kNX; ++i) {
+            const int idx = tid + i * 256, pix = idx >> psh, pc = idx & pm;
+            const int ph = pix / kHW, hh = h0 - 1 + ph, ww = w0 - 1 + pix - ph * kHW;
+            const bool ok = idx < nx && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            rx[i] = make_uint4(0, 0, 0, 0);
+            if (ok) rx[i] = *reinterpret_cast<const uint4 *>(xi + ((int64_t)hh * W + ww) * Ci + k0 + pc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < kNW; ++i) {
+            const int idx = tid + i * 256, row = idx >> psh, pc = idx & pm;          // row = tap * (NB*16) + col
+            const int tap = row / (NB * 16), col = row - tap * (NB * 16);
+            rw[i] = make_uint4(0, 0, 0, 0);
+            if (idx < nw && co0 + col < Co) rw[i] = *reinterpret_cast<const uint4 *>(w + ((int64_t)(co0 + col) * 9 + tap) * Ci + k0 + pc * 8);
+        }
+    };
+    auto put = [&](int ks) {
+        const int psh = ks == kKS ? 2 : 1, pm = (1 << psh) - 1;
+        const int nx = (kHH * kHW) << psh, nw = (9 * NB * 16) << psh;
+#pragma unroll
+        for (int i = 0; i < kNX; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < nx) *reinterpret_cast<uint4 *>(sX + (idx >> psh) * kXP + (idx & pm) * 8) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kNW; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < nw) *reinterpret_cast<uint4 *>(sW + (idx >> psh) * kWP + (idx & pm) * 8) = rw[i];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Ci; k0 += kKS) {
+        const int ks = min(kKS, Ci - k0);                       // channels in this slice: 32, or a 16-channel tail
+        __syncthreads();                                        // the previous slice's fragments have been read
+        put(ks);
+        __syncthreads();
+        if (k0 + kKS < Ci) fetch(k0 + kKS);                     // in flight during the products below
+        if (ks == kKS) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+                // fragments: 16 pixels of one image row (fr) x 8 consecutive channels (fq)
+                bf16x8 a[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    a[m] = *reinterpret_cast<const bf16x8 *>(sX + ((wv * 2 + m + dy) * kHW + fr + dx) * kXP + fq * 8);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(sW + ((tap * NB + n) * 16 + fr) * kWP + fq * 8);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[m], acc[m][n], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
                 // A fragments: 16 pixels of one image row (fr) x 4 consecutive channels (fq) -> rows (wv*2 + m + dy), cols (fr + dx)
                 bf16x4 a[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    a[m] = *reinterpret_cast<const bf16x4 *>(sX + ((wv * 2 + m + dy) * kHW + fr + dx) * kXP + kk + fq * 4);
+                    a[m] = *reinterpret_cast<const bf16x4 *>(sX + ((wv * 2 + m + dy) * kHW + fr + dx) * kXP + fq * 4);
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    const bf16x4 b = *reinterpret_cast<const bf16x4 *>(sW + ((tap * NB + n) * 16 + fr) * kWP + kk + fq * 4);
+                    const bf16x4 b = *reinterpret_cast<const bf16x4 *>(sW + ((tap * NB + n) * 16 + fr) * kWP + fq * 4);
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b, a[m], acc[m][n], 0, 0, 0);
@@ -157,27 +204,46 @@ conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short 
 #pragma unroll
         for (int j = 0; j < kMaxCols; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // staging through registers, one tile ahead: the next tile's 16-byte loads (<= 8 per thread) are in flight while this tile
+    // is multiplied (same scheme as the forward kernel above)
+    constexpr int kPC = kGC / 8;                                        // 16-byte pieces per pixel
+    constexpr int kNX = (kHH * kHW * kPC + 255) / 256, kNG = (kTH * kTW * kPC + 255) / 256;
+    uint4 rx[kNX], rg[kNG];
+    auto fetch = [&](int tile) {
         const int img = tile / tiles_per_img, tt = tile - img * tiles_per_img;
         const int h0 = (tt / tiles_w) * kTH, w0 = (tt % tiles_w) * kTW;
-        __syncthreads();
-        for (int idx = tid; idx < kHH * kHW * (kGC / 8); idx += 256) {
-            const int pix = idx / (kGC / 8), pc = idx - pix * (kGC / 8);
-            const int hh = h0 - 1 + pix / kHW, ww = w0 - 1 + pix % kHW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W && ci0 + pc * 8 < Ci)
-                v = *reinterpret_cast<const uint4 *>(x + (((int64_t)img * H + hh) * W + ww) * Ci + ci0 + pc * 8);
-            *reinterpret_cast<uint4 *>(sX + pix * kGP + pc * 8) = v;
+#pragma unroll
+        for (int i = 0; i < kNX; ++i) {
+            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
+            const int ph = pix / kHW, hh = h0 - 1 + ph, ww = w0 - 1 + pix - ph * kHW;
+            rx[i] = make_uint4(0, 0, 0, 0);
+            if (idx < kHH * kHW * kPC && hh >= 0 && hh < H && ww >= 0 && ww < W && ci0 + pc * 8 < Ci)
+                rx[i] = *reinterpret_cast<const uint4 *>(x + (((int64_t)img * H + hh) * W + ww) * Ci + ci0 + pc * 8);
         }
-        for (int idx = tid; idx < kTH * kTW * (kGC / 8); idx += 256) {
-            const int pix = idx / (kGC / 8), pc = idx - pix * (kGC / 8);
+#pragma unroll
+        for (int i = 0; i < kNG; ++i) {
+            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
             const int hh = h0 + pix / kTW, ww = w0 + pix % kTW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hh < H && ww < W && co0 + pc * 8 < Co)
-                v = *reinterpret_cast<const uint4 *>(dy + (((int64_t)img * H + hh) * W + ww) * Co + co0 + pc * 8);
-            *reinterpret_cast<uint4 *>(sG + pix * kGP + pc * 8) = v;
+            rg[i] = make_uint4(0, 0, 0, 0);
+            if (idx < kTH * kTW * kPC && hh < H && ww < W && co0 + pc * 8 < Co)
+                rg[i] = *reinterpret_cast<const uint4 *>(dy + (((int64_t)img * H + hh) * W + ww) * Co + co0 + pc * 8);
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kNX; ++i) {
+            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
+            if (idx < kHH * kHW * kPC) *reinterpret_cast<uint4 *>(sX + pix * kGP + pc * 8) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kNG; ++i) {
+            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
+            if (idx < kTH * kTW * kPC) *reinterpret_cast<uint4 *>(sG + pix * kGP + pc * 8) = rg[i];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
 #pragma unroll 2
         for (int r = 0; r < kTH; ++r) {
             bf16x4 ga[3];

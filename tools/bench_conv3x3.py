@@ -27,7 +27,7 @@ for C, Hh in [(48, 56), (96, 28), (192, 14), (384, 7)]:
     t_ms = cold(run); t_mi = cold(lambda: F.conv2d(x, w, padding=1))
     print(f"C={C:4d} {Hh}x{Hh}: ms {t_ms:6.1f} us  MIOpen {t_mi:6.1f} us   max rel err {err:.2e}", flush=True)
     # weight gradient: ms_conv3x3_wgrad (main + finalize) vs MIOpen's (incl. its helper launches)
-    if Hh * Hh >= 196:
+    if True:
         dy = torch.randn_like(x)
         ns = lib.ms_conv3x3_wgrad_scratch_floats(bs, Hh, Hh, C, C)
         scratch = torch.empty(ns, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)
