@@ -349,7 +349,34 @@ typedef struct MsCastDesc {
     int64_t n;
     int32_t inner, taps;
 } MsCastDesc;
-int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream);
+/* `blocks` (device memory): n_blocks pairs (tensor index, piece index), every piece of every tensor exactly once.  Pieces of a
+ * tensor: plain casts and tap counts above MS_CAST_TILE_MAX_TAPS -- ceil(n / MS_CAST_CHUNK) runs of consecutive elements;
+ * convolution weights with 2..MS_CAST_TILE_MAX_TAPS taps -- ceil(O / MS_CAST_TILE_O) * ceil(inner / MS_CAST_TILE_I) tiles, piece =
+ * o_tile * ceil(inner / MS_CAST_TILE_I) + i_tile. */
+#define MS_CAST_CHUNK 2048
+#define MS_CAST_TILE_O 64
+#define MS_CAST_TILE_I 16
+#define MS_CAST_TILE_MAX_TAPS 9
+int ms_cast_bf16_multi(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, void *stream);
+
+/* ---- `optimizer.step()` of the training loop: Adam over all parameters in one launch (/root/reference/train.py:62,76:
+ * `optim.Adam(net.parameters(), lr=0.0001)`: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) ---------------------------
+ *   desc   (device memory) one entry per parameter tensor: fp32 parameter, exp_avg, exp_avg_sq and the element count
+ *   blocks (device memory) n_blocks pairs (tensor index, chunk index): workgroup b updates elements
+ *          [chunk * MS_ADAM_CHUNK, min(n, (chunk + 1) * MS_ADAM_CHUNK)) of its tensor; every chunk of every tensor exactly once
+ *   grads  (HOST memory) n_tensors <= MS_ADAM_MAX_TENSORS device pointers to the fp32 gradients (they are new tensors after every
+ *          backward pass: they travel as kernel arguments, the rest of the table is built once)
+ *   m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;  p -= step_size m / (sqrt(v) / bias_correction2_sqrt + eps)
+ *   with step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) formed by the caller (torch.optim.Adam's rule). */
+#define MS_ADAM_CHUNK 4096
+#define MS_ADAM_MAX_TENSORS 448
+typedef struct MsAdamDesc {
+    float *p, *m, *v;
+    int64_t n;
+} MsAdamDesc;
+int ms_adam_multi(const MsAdamDesc *desc, const int32_t *blocks, int n_blocks, const void *const *grads, int n_tensors,
+                  float step_size, float bias_correction2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps,
+                  void *stream);
 
 /* ---- dense 3x3 convolution of the conv branch (`nn.Conv2d(dim/2, dim/2, 3, padding=1)`, MedMamba.py:518-523) ---------------------
  * stride 1, padding 1, groups 1, no bias; x (batch, H, W, Ci), y (batch, H, W, Co) bf16 channels_last memory; w bf16 in

@@ -43,7 +43,10 @@ int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int 
 int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W,
                            int Ci, int Co, hipStream_t s);
 int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
-int cast_bf16_multi_dispatch(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, hipStream_t s);
+int cast_bf16_multi_dispatch(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, hipStream_t s);
+int adam_multi_dispatch(const MsAdamDesc *desc, const int32_t *blocks, int n_blocks, const void *const *grads, int n_tensors,
+                        float step_size, float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps,
+                        hipStream_t s);
 int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
                     int out_bf16, int64_t npix, int D, hipStream_t s);
 int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
@@ -92,8 +95,15 @@ int64_t ms_conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co)
 
 int ms_debug_gemm_tile(int bm, int bn) { ms::gemm_debug_tile(bm, bn); return MS_OK; }
 
-int ms_cast_bf16_multi(const MsCastDesc *desc, int n_tensors, int blocks_per_tensor, void *stream) {
-    return ms::cast_bf16_multi_dispatch(desc, n_tensors, blocks_per_tensor, (hipStream_t)stream);
+int ms_cast_bf16_multi(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, void *stream) {
+    return ms::cast_bf16_multi_dispatch(desc, blocks, n_blocks, (hipStream_t)stream);
+}
+
+int ms_adam_multi(const MsAdamDesc *desc, const int32_t *blocks, int n_blocks, const void *const *grads, int n_tensors,
+                  float step_size, float bias_correction2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps,
+                  void *stream) {
+    return ms::adam_multi_dispatch(desc, blocks, n_blocks, grads, n_tensors, step_size, bias_correction2_sqrt, one_minus_beta1, beta2,
+                                   one_minus_beta2, eps, (hipStream_t)stream);
 }
 
 int ms_block_head_bwd(const float *dout, const void *dleft, int dleft_is_bf16, const void *dright, int dright_is_bf16, float *dinput,

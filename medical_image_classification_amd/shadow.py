@@ -41,7 +41,7 @@ class _Registry:
     def __init__(self):
         self.params = []          # ids, registration order
         self.epoch = 0
-        self.table = None         # (key, device tensor holding the descriptors, n, blocks)
+        self.table = None         # (key, device tensor holding the descriptors, device block table, n_blocks)
 
 
 _REG = {}
@@ -98,7 +98,7 @@ def _refresh(reg, device, only=None):
     key = tuple((p.data_ptr(), sh.t.data_ptr(), p.numel(), (tuple(p.shape), sh.conv) if sh.conv else 0) for p, sh in todo)
     if only is not None or reg.table is None or reg.table[0] != key:
         arr = (MsCastDesc * len(todo))()
-        biggest = 1
+        blocks = []
         for i, (p, sh) in enumerate(todo):
             taps = p.shape[2] * p.shape[3] if (sh.conv and p.dim() == 4) else 1
             arr[i].src, arr[i].dst, arr[i].n = p.data_ptr(), sh.t.data_ptr(), p.numel()
@@ -106,17 +106,21 @@ def _refresh(reg, device, only=None):
                 arr[i].inner, arr[i].taps = p.shape[1], -taps
             else:
                 arr[i].inner, arr[i].taps = (p.shape[1] if taps > 1 else 1), taps
-            biggest = max(biggest, p.numel())
+            if 2 <= taps <= _lib.CAST_TILE_MAX_TAPS:        # convolution weights: tiles of 64 output x 16 input channels
+                pieces = -(-p.shape[0] // _lib.CAST_TILE_O) * -(-p.shape[1] // _lib.CAST_TILE_I)
+            else:
+                pieces = -(-p.numel() // _lib.CAST_CHUNK)
+            blocks.extend((i, c) for c in range(pieces))
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        blocks = max(1, min(64, (biggest + 2047) // 2048))
-        table = (key, host.to(device), len(todo), blocks)
+        bt = torch.tensor(blocks, dtype=torch.int32).reshape(-1, 2).contiguous()
+        table = (key, host.to(device), bt.to(device), len(blocks))
         if only is None:
             reg.table = table                      # (a one-off table is not worth caching over the whole-model one)
     else:
         table = reg.table
-    _, tab, n, blocks = table
+    _, tab, bt, n_blocks = table
     with _lib.on_device(device):
-        _lib.check(_lib.lib().ms_cast_bf16_multi(tab.data_ptr(), n, blocks, _lib.current_stream_ptr(device)), "ms_cast_bf16_multi")
+        _lib.check(_lib.lib().ms_cast_bf16_multi(tab.data_ptr(), bt.data_ptr(), n_blocks, _lib.current_stream_ptr(device)), "ms_cast_bf16_multi")
     for p, sh in todo:
         sh.version, sh.ptr, sh.epoch = p._version, p.data_ptr(), reg.epoch
 

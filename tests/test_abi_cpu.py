@@ -33,20 +33,22 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_layout_matches_c(tmp_path):
     """sizeof/offsetof of the ctypes mirrors == what a C compiler sees in medscan.h."""
-    from medical_image_classification_amd._lib import MsCastDesc, MsScanBwdParams, MsScanParams
+    from medical_image_classification_amd._lib import ADAM_CHUNK, ADAM_MAX_TENSORS, MsAdamDesc, MsCastDesc, MsScanBwdParams, MsScanParams
     src = tmp_path / "lay.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "medscan.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(MsScanParams),offsetof(MsScanParams,u),offsetof(MsScanParams,x),sizeof(MsScanBwdParams),'
                    'offsetof(MsScanBwdParams,dout),offsetof(MsScanBwdParams,ddelta_bias));'
                    'printf("%zu %zu %zu\\n",offsetof(MsScanParams,dt_w),offsetof(MsScanParams,dt_rank),offsetof(MsScanBwdParams,ddt_w));'
-                   'printf("%zu %zu %zu\\n",sizeof(MsCastDesc),offsetof(MsCastDesc,n),offsetof(MsCastDesc,taps));return 0;}\n')
+                   'printf("%zu %zu %zu\\n",sizeof(MsCastDesc),offsetof(MsCastDesc,n),offsetof(MsCastDesc,taps));'
+                   'printf("%zu %zu %d %d\\n",sizeof(MsAdamDesc),offsetof(MsAdamDesc,n),MS_ADAM_CHUNK,MS_ADAM_MAX_TENSORS);return 0;}\n')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(MsScanParams), MsScanParams.u.offset, MsScanParams.x.offset,
             ctypes.sizeof(MsScanBwdParams), MsScanBwdParams.dout.offset, MsScanBwdParams.ddelta_bias.offset,
             MsScanParams.dt_w.offset, MsScanParams.dt_rank.offset, MsScanBwdParams.ddt_w.offset,
-            ctypes.sizeof(MsCastDesc), MsCastDesc.n.offset, MsCastDesc.taps.offset]
+            ctypes.sizeof(MsCastDesc), MsCastDesc.n.offset, MsCastDesc.taps.offset,
+            ctypes.sizeof(MsAdamDesc), MsAdamDesc.n.offset, ADAM_CHUNK, ADAM_MAX_TENSORS]
     assert got == want
 
 
@@ -57,6 +59,8 @@ def test_null_and_shape_errors_without_gpu(lib):
     assert lib.ms_selective_scan_fwd(ctypes.byref(p), None) == -1      # NULL operands
     assert lib.ms_cross_scan(None, None, 1, 1, 1, 1, None) == -1
     assert lib.ms_dwconv3x3_silu_fwd(None, None, None, None, 1, 1, 1, 1, None) == -1
+    assert lib.ms_adam_multi(None, None, 1, None, 1, 1e-3, 1.0, 0.1, 0.999, 1e-3, 1e-8, None) == -1
+    assert lib.ms_adam_multi(None, None, 1, None, 449, 1e-3, 1.0, 0.1, 0.999, 1e-3, 1e-8, None) == -2      # more tensors than one launch carries
 
 
 def test_cpu_tensors_fail_loudly():
