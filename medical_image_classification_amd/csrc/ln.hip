@@ -6,6 +6,7 @@
 // One wave = one pixel (D channels, lane owns channels lane, lane+64, ...), 4 pixels per workgroup per iteration.
 #include <hip/hip_runtime.h>
 #include "medscan.h"
+#include "ln_common.h"
 
 namespace ms {
 
@@ -149,6 +150,170 @@ ln_bwd_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict_
     }
 }
 
+// ---- sub-wave pixel groups, 16-byte accesses, VALU all-reduces (ln_common.h): the kernels every aligned call takes ------------
+template <int LPP, int V4, int PB, typename TO>
+__global__ void __launch_bounds__(256)
+ln_fwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict__ gamma, const float *__restrict__ beta,
+                  float eps, TO *__restrict__ out, int D, int64_t npix) {
+    constexpr int PW = 64 / LPP;
+    const int lane = threadIdx.x & 63, lip = lane % LPP, sub = lane / LPP;
+    const int64_t p0 = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PB) * PW;
+    if (p0 >= npix) return;
+    const float invD = 1.0f / (float)D;
+    float4 v[PB][V4];
+    float s1[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t pix = min(p0 + q * PW + sub, npix - 1);
+        s1[q] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (lip + LPP * j);
+            v[q][j] = c < D ? ld4f(x + pix * xps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s1[q] += sum4(v[q][j]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) s1[q] = group_allsum<LPP>(s1[q], lane) * invD;
+    float s2[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        s2[q] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            if (4 * (lip + LPP * j) < D) {
+                const float a = v[q][j].x - s1[q], b = v[q][j].y - s1[q], c = v[q][j].z - s1[q], d = v[q][j].w - s1[q];
+                s2[q] += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) s2[q] = rsqrtf(group_allsum<LPP>(s2[q], lane) * invD + eps);
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t pix = p0 + q * PW + sub;
+        if (pix >= npix) continue;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (lip + LPP * j);
+            if (c < D) {
+                const float4 g = ld4f(gamma + c), b = ld4f(beta + c);
+                st4f(out + pix * D + c, make_float4((v[q][j].x - s1[q]) * s2[q] * g.x + b.x, (v[q][j].y - s1[q]) * s2[q] * g.y + b.y,
+                                                    (v[q][j].z - s1[q]) * s2[q] * g.z + b.z, (v[q][j].w - s1[q]) * s2[q] * g.w + b.w));
+            }
+        }
+    }
+}
+
+template <int LPP, int V4, int PB, typename TG>
+__global__ void __launch_bounds__(256)
+ln_bwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict__ gamma, float eps,
+                  const TG *__restrict__ dout, float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                  int D, int64_t npix) {
+    constexpr int PW = 64 / LPP, NC = 4 * V4 * LPP;                     // channel slots of a group
+    __shared__ __attribute__((aligned(16))) float red[4][2][NC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lip = lane % LPP, sub = lane / LPP;
+    float4 gm[V4], dg[V4], db[V4];
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const int c = 4 * (lip + LPP * j);
+        gm[j] = c < D ? ld4f(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[j] = make_float4(0.f, 0.f, 0.f, 0.f); db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // persistent waves (the dgamma / dbeta partial sums stay in registers over all of a wave's pixels)
+    const int64_t step = (int64_t)gridDim.x * 4 * PB * PW;
+    const float invD = 1.0f / (float)D;
+    for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB * PW; p0 < npix; p0 += step) {
+        float4 v[PB][V4], g[PB][V4];
+        float s1[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int64_t pix = min(p0 + q * PW + sub, npix - 1);       // duplicates of the last pixel are computed, not stored
+            s1[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const int c = 4 * (lip + LPP * j);
+                const bool in = c < D;
+                v[q][j] = in ? ld4f(x + pix * xps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g[q][j] = in ? ld4f(dout + pix * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s1[q] += sum4(v[q][j]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) s1[q] = group_allsum<LPP>(s1[q], lane) * invD;
+        float s2[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            s2[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                if (4 * (lip + LPP * j) < D) {
+                    const float a = v[q][j].x - s1[q], b = v[q][j].y - s1[q], c = v[q][j].z - s1[q], d = v[q][j].w - s1[q];
+                    s2[q] += (a * a + b * b) + (c * c + d * d);
+                }
+            }
+        }
+        float m1[PB], m2[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const float rstd = rsqrtf(group_allsum<LPP>(s2[q], lane) * invD + eps);
+            const bool live = p0 + q * PW + sub < npix;
+            s2[q] = rstd;
+            m1[q] = 0.0f; m2[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const bool in = 4 * (lip + LPP * j) < D;
+                float4 &vv = v[q][j], &gg = g[q][j];
+                vv.x = in ? (vv.x - s1[q]) * rstd : 0.0f; vv.y = in ? (vv.y - s1[q]) * rstd : 0.0f;      // normalised values
+                vv.z = in ? (vv.z - s1[q]) * rstd : 0.0f; vv.w = in ? (vv.w - s1[q]) * rstd : 0.0f;
+                if (live) {
+                    dg[j].x = fmaf(gg.x, vv.x, dg[j].x); dg[j].y = fmaf(gg.y, vv.y, dg[j].y);
+                    dg[j].z = fmaf(gg.z, vv.z, dg[j].z); dg[j].w = fmaf(gg.w, vv.w, dg[j].w);
+                    db[j].x += gg.x; db[j].y += gg.y; db[j].z += gg.z; db[j].w += gg.w;
+                }
+                gg.x *= gm[j].x; gg.y *= gm[j].y; gg.z *= gm[j].z; gg.w *= gm[j].w;                      // gradient w.r.t. the normalised value
+                m1[q] += sum4(gg);
+                m2[q] += (gg.x * vv.x + gg.y * vv.y) + (gg.z * vv.z + gg.w * vv.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) { m1[q] = group_allsum<LPP>(m1[q], lane) * invD; m2[q] = group_allsum<LPP>(m2[q], lane) * invD; }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int64_t pix = p0 + q * PW + sub;
+            if (pix >= npix) continue;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const int c = 4 * (lip + LPP * j);
+                if (c < D) {
+                    const float4 vv = v[q][j], gg = g[q][j];
+                    st4f(dx + pix * D + c, make_float4(s2[q] * (gg.x - m1[q] - vv.x * m2[q]), s2[q] * (gg.y - m1[q] - vv.y * m2[q]),
+                                                       s2[q] * (gg.z - m1[q] - vv.z * m2[q]), s2[q] * (gg.w - m1[q] - vv.w * m2[q])));
+                }
+            }
+        }
+    }
+    // gamma / beta gradients: the wave's pixel groups (registers), the block's 4 waves (LDS), one atomic per (block, channel)
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        dg[j].x = across_groups<LPP>(dg[j].x, lane); dg[j].y = across_groups<LPP>(dg[j].y, lane);
+        dg[j].z = across_groups<LPP>(dg[j].z, lane); dg[j].w = across_groups<LPP>(dg[j].w, lane);
+        db[j].x = across_groups<LPP>(db[j].x, lane); db[j].y = across_groups<LPP>(db[j].y, lane);
+        db[j].z = across_groups<LPP>(db[j].z, lane); db[j].w = across_groups<LPP>(db[j].w, lane);
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < V4; ++j) { st4f(&red[wv][0][4 * (lip + LPP * j)], dg[j]); st4f(&red[wv][1][4 * (lip + LPP * j)], db[j]); }
+    }
+    __syncthreads();
+    // consecutive threads -> consecutive channels: a wave's atomics cover whole 256-byte segments (4 per lane at 16-byte strides
+    // quadrupled the cache lines per instruction, and the closing burst of same-address atomics is what bounds this kernel)
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
+        atomicAdd(dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
+    }
+}
+
 #define MS_LN_DISPATCH(VPTVAR, CALL)                                                                            \
     if (VPTVAR <= 1) { CALL(1); } else if (VPTVAR <= 2) { CALL(2); } else if (VPTVAR <= 3) { CALL(3); }           \
     else if (VPTVAR <= 4) { CALL(4); } else if (VPTVAR <= 6) { CALL(6); } else if (VPTVAR <= 8) { CALL(8); }      \
@@ -159,6 +324,15 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
     if (!x || !gamma || !beta || !out) return MS_ERR_NULL;
     if (D <= 0 || D > 64 * kLnMaxVPT || npix < 0 || xps < D) return MS_ERR_SHAPE;
     if (npix == 0) return MS_OK;
+    if (D % 4 == 0 && xps % 4 == 0 && ln_aligned(x, 16) && ln_aligned(gamma, 16) && ln_aligned(beta, 16) && ln_aligned(out, out_bf16 ? 8 : 16)) {
+#define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                           \
+        const dim3 g((unsigned)((npix + per - 1) / per));                                                                       \
+        if (out_bf16) hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (unsigned short *)out, D, npix); \
+        else hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (float *)out, D, npix); } while (0)
+        MS_LN_SUB_DISPATCH(D, MS_S)
+#undef MS_S
+        return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+    }
     const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
     const int vpt = (D + 63) / 64;
     if (out_bf16) {
@@ -178,6 +352,19 @@ int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, 
     if (!x || !gamma || !dout || !dx || !dgamma || !dbeta) return MS_ERR_NULL;
     if (D <= 0 || D > 64 * kLnMaxVPT || npix < 0 || xps < D) return MS_ERR_SHAPE;
     if (npix == 0) return MS_OK;
+    if (D % 4 == 0 && xps % 4 == 0 && ln_aligned(x, 16) && ln_aligned(gamma, 16) && ln_aligned(dx, 16) && ln_aligned(dout, dout_bf16 ? 8 : 16)) {
+        // persistent blocks: enough to keep HBM busy, few enough that the closing burst of same-address dgamma / dbeta atomics
+        // (~40 ns each per address) stays short -- swept 64..2048 at the four stage shapes (tools/bench_ln.py)
+        const int64_t cap2 = npix >= 32768 ? 512 : 256;
+#define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                           \
+        const int64_t nb = (npix + per - 1) / per;                                                                              \
+        const dim3 g((unsigned)(nb < cap2 ? nb : cap2));                                                                        \
+        if (dout_bf16) hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix); \
+        else hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix); } while (0)
+        MS_LN_SUB_DISPATCH(D, MS_S)
+#undef MS_S
+        return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+    }
     const int vpt = (D + 63) / 64;
     const int pb = vpt <= 2 ? 4 : vpt <= 4 ? 2 : 1;                 // = MS_PB of the dispatched VPT bucket
     const int64_t tasks = (npix + pb - 1) / pb;                     // pixel groups

@@ -7,6 +7,7 @@
 // One wave = one pixel (D channels, lane owns channels lane, lane+64, ...), 4 pixels per workgroup per iteration.
 #include <hip/hip_runtime.h>
 #include "medscan.h"
+#include "ln_common.h"
 
 namespace ms {
 
@@ -176,9 +177,205 @@ ln_gate_bwd_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restric
     }
 }
 
+// ---- sub-wave pixel groups, 16-byte accesses, VALU all-reduces (ln_common.h): the kernels every aligned call takes ------------
+__device__ __forceinline__ float4 merge4(const float *yp, int64_t sk, int c) {
+    if (sk == 0) return ld4f(yp + c);                                   // the merged sum itself
+    const float4 a = ld4f(yp + c), b = ld4f(yp + sk + c), d = ld4f(yp + 2 * sk + c), e = ld4f(yp + 3 * sk + c);
+    return make_float4(((a.x + d.x) + b.x) + e.x, ((a.y + d.y) + b.y) + e.y, ((a.z + d.z) + b.z) + e.z, ((a.w + d.w) + b.w) + e.w);
+}
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+
+template <int LPP, int V4, int PB, typename TZ, typename TO>
+__global__ void __launch_bounds__(256)
+ln_gate_fwd_sub_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restrict__ z, int64_t zps,
+                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                       TO *__restrict__ out, float *__restrict__ ysum, int D, int64_t npix) {
+    constexpr int PW = 64 / LPP;
+    const int lane = threadIdx.x & 63, lip = lane % LPP, sub = lane / LPP;
+    const int64_t p0 = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PB) * PW;
+    if (p0 >= npix) return;
+    const float invD = 1.0f / (float)D;
+    float4 v[PB][V4];
+    float s1[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t pr = p0 + q * PW + sub, pix = min(pr, npix - 1);
+        s1[q] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (lip + LPP * j);
+            v[q][j] = c < D ? merge4(y4 + pix * D, sk, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s1[q] += sum4(v[q][j]);
+            if (ysum && c < D && pr < npix) st4f(ysum + pix * D + c, v[q][j]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) s1[q] = group_allsum<LPP>(s1[q], lane) * invD;
+    float s2[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        s2[q] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            if (4 * (lip + LPP * j) < D) {
+                const float a = v[q][j].x - s1[q], b = v[q][j].y - s1[q], c = v[q][j].z - s1[q], d = v[q][j].w - s1[q];
+                s2[q] += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) s2[q] = rsqrtf(group_allsum<LPP>(s2[q], lane) * invD + eps);
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t pix = p0 + q * PW + sub;
+        if (pix >= npix) continue;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (lip + LPP * j);
+            if (c < D) {
+                const float4 g = ld4f(gamma + c), b = ld4f(beta + c), zz = ld4f(z + pix * zps + c);
+                st4f(out + pix * D + c, make_float4(((v[q][j].x - s1[q]) * s2[q] * g.x + b.x) * silu_f(zz.x),
+                                                    ((v[q][j].y - s1[q]) * s2[q] * g.y + b.y) * silu_f(zz.y),
+                                                    ((v[q][j].z - s1[q]) * s2[q] * g.z + b.z) * silu_f(zz.z),
+                                                    ((v[q][j].w - s1[q]) * s2[q] * g.w + b.w) * silu_f(zz.w)));
+            }
+        }
+    }
+}
+
+// one channel of the backward: dz, and the pieces the LayerNorm backward needs (normalised value yn, gradient g w.r.t. it)
+__device__ __forceinline__ void gate_bwd_1(float y, float z, float go, float mean, float rstd, float gm, float bt, bool in, bool live,
+                                           float &dzv, float &yn, float &gv, float &dg, float &db) {
+    const float sg = 1.0f / (1.0f + expf(-z));
+    yn = in ? (y - mean) * rstd : 0.0f;
+    const float yh = yn * gm + bt;
+    dzv = go * yh * (sg * (1.0f + z * (1.0f - sg)));
+    const float dyh = in ? go * (z * sg) : 0.0f;
+    if (live) { dg = fmaf(dyh, yn, dg); db += dyh; }
+    gv = dyh * gm;
+}
+
+template <int LPP, int V4, int PB, typename TZ, typename TG>
+__global__ void __launch_bounds__(256)
+ln_gate_bwd_sub_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restrict__ z, int64_t zps,
+                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                       const TG *__restrict__ dout, float *__restrict__ dy, TZ *__restrict__ dz,
+                       float *__restrict__ dgamma, float *__restrict__ dbeta, int D, int64_t npix, int64_t dzps) {
+    constexpr int PW = 64 / LPP, NC = 4 * V4 * LPP;
+    __shared__ __attribute__((aligned(16))) float red[4][2][NC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lip = lane % LPP, sub = lane / LPP;
+    float4 gm[V4], bt[V4], dg[V4], db[V4];
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const int c = 4 * (lip + LPP * j);
+        gm[j] = c < D ? ld4f(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[j] = c < D ? ld4f(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[j] = make_float4(0.f, 0.f, 0.f, 0.f); db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int64_t step = (int64_t)gridDim.x * 4 * PB * PW;
+    const float invD = 1.0f / (float)D;
+    for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB * PW; p0 < npix; p0 += step) {
+        float4 y[PB][V4], zz[PB][V4], g[PB][V4];
+        float s1[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int64_t pix = min(p0 + q * PW + sub, npix - 1);       // duplicates of the last pixel are computed, not stored
+            s1[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const int c = 4 * (lip + LPP * j);
+                const bool in = c < D;
+                y[q][j] = in ? merge4(y4 + pix * D, sk, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                zz[q][j] = in ? ld4f(z + pix * zps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g[q][j] = in ? ld4f(dout + pix * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s1[q] += sum4(y[q][j]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) s1[q] = group_allsum<LPP>(s1[q], lane) * invD;
+        float s2[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            s2[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                if (4 * (lip + LPP * j) < D) {
+                    const float a = y[q][j].x - s1[q], b = y[q][j].y - s1[q], c = y[q][j].z - s1[q], d = y[q][j].w - s1[q];
+                    s2[q] += (a * a + b * b) + (c * c + d * d);
+                }
+            }
+        }
+        float m1[PB], m2[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const float rstd = rsqrtf(group_allsum<LPP>(s2[q], lane) * invD + eps);
+            const int64_t pix = p0 + q * PW + sub;
+            const bool live = pix < npix;
+            s2[q] = rstd;
+            m1[q] = 0.0f; m2[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const int c = 4 * (lip + LPP * j);
+                const bool in = c < D;
+                float4 dzv, yn, gv;
+                gate_bwd_1(y[q][j].x, zz[q][j].x, g[q][j].x, s1[q], rstd, gm[j].x, bt[j].x, in, live, dzv.x, yn.x, gv.x, dg[j].x, db[j].x);
+                gate_bwd_1(y[q][j].y, zz[q][j].y, g[q][j].y, s1[q], rstd, gm[j].y, bt[j].y, in, live, dzv.y, yn.y, gv.y, dg[j].y, db[j].y);
+                gate_bwd_1(y[q][j].z, zz[q][j].z, g[q][j].z, s1[q], rstd, gm[j].z, bt[j].z, in, live, dzv.z, yn.z, gv.z, dg[j].z, db[j].z);
+                gate_bwd_1(y[q][j].w, zz[q][j].w, g[q][j].w, s1[q], rstd, gm[j].w, bt[j].w, in, live, dzv.w, yn.w, gv.w, dg[j].w, db[j].w);
+                if (in && live) st4f(dz + pix * dzps + c, dzv);
+                y[q][j] = yn; g[q][j] = gv;
+                m1[q] += sum4(gv);
+                m2[q] += (gv.x * yn.x + gv.y * yn.y) + (gv.z * yn.z + gv.w * yn.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) { m1[q] = group_allsum<LPP>(m1[q], lane) * invD; m2[q] = group_allsum<LPP>(m2[q], lane) * invD; }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int64_t pix = p0 + q * PW + sub;
+            if (pix >= npix) continue;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const int c = 4 * (lip + LPP * j);
+                if (c < D) {
+                    const float4 yn = y[q][j], gv = g[q][j];
+                    st4f(dy + pix * D + c, make_float4(s2[q] * (gv.x - m1[q] - yn.x * m2[q]), s2[q] * (gv.y - m1[q] - yn.y * m2[q]),
+                                                       s2[q] * (gv.z - m1[q] - yn.z * m2[q]), s2[q] * (gv.w - m1[q] - yn.w * m2[q])));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        dg[j].x = across_groups<LPP>(dg[j].x, lane); dg[j].y = across_groups<LPP>(dg[j].y, lane);
+        dg[j].z = across_groups<LPP>(dg[j].z, lane); dg[j].w = across_groups<LPP>(dg[j].w, lane);
+        db[j].x = across_groups<LPP>(db[j].x, lane); db[j].y = across_groups<LPP>(db[j].y, lane);
+        db[j].z = across_groups<LPP>(db[j].z, lane); db[j].w = across_groups<LPP>(db[j].w, lane);
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < V4; ++j) { st4f(&red[wv][0][4 * (lip + LPP * j)], dg[j]); st4f(&red[wv][1][4 * (lip + LPP * j)], db[j]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {          // consecutive threads -> consecutive channels: whole-segment atomics
+        atomicAdd(dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
+        atomicAdd(dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
+    }
+}
+
 template <typename TZ, typename TO>
 static int launch_fwd(const float *y4, int64_t sk, const void *z, int64_t zps, const float *gamma, const float *beta,
                       float eps, void *out, float *ysum, int D, int64_t npix, hipStream_t s) {
+    constexpr unsigned za = sizeof(TZ) == 2 ? 8 : 16, oa = sizeof(TO) == 2 ? 8 : 16;
+    if (D % 4 == 0 && sk % 4 == 0 && zps % 4 == 0 && ln_aligned(y4, 16) && ln_aligned(z, za) && ln_aligned(out, oa) && ln_aligned(gamma, 16) &&
+        ln_aligned(beta, 16) && (!ysum || ln_aligned(ysum, 16))) {
+#define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                      \
+        hipLaunchKernelGGL((ln_gate_fwd_sub_kernel<L, V, P, TZ, TO>), dim3((unsigned)((npix + per - 1) / per)), dim3(256), 0, s, y4, sk,   \
+                           (const TZ *)z, zps, gamma, beta, eps, (TO *)out, ysum, D, npix); } while (0)
+        MS_LN_SUB_DISPATCH(D, MS_S)
+#undef MS_S
+        return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+    }
     const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
     const int vpt = (D + 63) / 64;
 #define MS_L(V) hipLaunchKernelGGL((ln_gate_fwd_kernel<V, TZ, TO>), grid, block, 0, s, y4, sk, (const TZ *)z, zps, gamma, beta, eps, (TO *)out, ysum, D, npix)
@@ -203,6 +400,21 @@ template <typename TZ, typename TG>
 static int launch_bwd(const float *y4, int64_t sk, const void *z, int64_t zps, const float *gamma, const float *beta,
                       float eps, const void *dout, float *dy, void *dz, int64_t dzps, float *dgamma, float *dbeta, int D,
                       int64_t npix, hipStream_t s) {
+    constexpr unsigned za = sizeof(TZ) == 2 ? 8 : 16, ga = sizeof(TG) == 2 ? 8 : 16;
+    if (D % 4 == 0 && sk % 4 == 0 && zps % 4 == 0 && dzps % 4 == 0 && ln_aligned(y4, 16) && ln_aligned(z, za) && ln_aligned(dz, za) &&
+        ln_aligned(dout, ga) && ln_aligned(dy, 16) && ln_aligned(gamma, 16) && ln_aligned(beta, 16)) {
+        // persistent blocks, swept 256..4096 at the four stage shapes with the merged input (tools/bench_ln.py): more bytes per pixel
+        // than the plain LayerNorm backward, so the optimum sits at more blocks; beyond it the closing burst of same-address
+        // dgamma / dbeta atomics (~40 ns each per address) takes over
+        const int64_t cap2 = npix >= 131072 ? 2048 : npix >= 8192 ? 512 : 256;
+#define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                      \
+        const int64_t nb = (npix + per - 1) / per;                                                                         \
+        hipLaunchKernelGGL((ln_gate_bwd_sub_kernel<L, V, P, TZ, TG>), dim3((unsigned)(nb < cap2 ? nb : cap2)), dim3(256), 0, s, y4, sk,    \
+                           (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix, dzps); } while (0)
+        MS_LN_SUB_DISPATCH(D, MS_S)
+#undef MS_S
+        return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+    }
     const int vpt = (D + 63) / 64;
     const int pb = vpt <= 2 ? 4 : vpt <= 4 ? 2 : 1;                 // = MS_PB of the dispatched VPT bucket
     const int64_t tasks = (npix + pb - 1) / pb;                     // pixel groups

@@ -30,6 +30,11 @@ for D, Hh, bs in SHAPES:
                                  dy.data_ptr(), dz.data_ptr(), D, dgb[0].data_ptr(), dgb[1].data_ptr(), npix, D, st())
     bytes_b = npix * D * (16 + 2 + 2 + 4 + 2)
     tf, tb = timeit(f), timeit(b)
+    ysum = torch.empty(npix, D, device=dev)
+    fk = lambda: h.ms_ln_gate_fwd_keep(y4.data_ptr(), npix * D, z.data_ptr(), 1, D, gm.data_ptr(), bt.data_ptr(), 1e-5, out.data_ptr(), 1, ysum.data_ptr(), npix, D, st())
+    bm = lambda: h.ms_ln_gate_bwd(ysum.data_ptr(), 0, z.data_ptr(), 1, D, gm.data_ptr(), bt.data_ptr(), 1e-5, dout.data_ptr(), 1,
+                                  dy.data_ptr(), dz.data_ptr(), D, dgb[0].data_ptr(), dgb[1].data_ptr(), npix, D, st())
+    tfk, tbm = timeit(fk), timeit(bm)
     Dh = D // 2
     x = torch.randn(npix, 2 * Dh, device=dev); g2, b2 = torch.randn(Dh, device=dev), torch.randn(Dh, device=dev)
     o2 = torch.empty(npix, Dh, device=dev, dtype=torch.bfloat16); do2 = torch.randn(npix, Dh, device=dev).bfloat16()
@@ -39,5 +44,5 @@ for D, Hh, bs in SHAPES:
     lb = lambda: h.ms_layernorm_bwd(xr.data_ptr(), 2 * Dh, g2.data_ptr(), 1e-6, do2.data_ptr(), 1, dx2.data_ptr(), dgb[0].data_ptr(),
                                     dgb[1].data_ptr(), npix, Dh, st())
     tlf, tlb = timeit(lf), timeit(lb)
-    print(f"D={D:4d} npix={npix:7d}: ln_gate fwd {tf:7.1f} us  bwd {tb:7.1f} us ({bytes_b / tb / 1e6:5.2f} TB/s) | ln fwd {tlf:6.1f} us  bwd {tlb:6.1f} us "
+    print(f"D={D:4d} npix={npix:7d}: ln_gate fwd {tf:7.1f} (keep {tfk:6.1f}) us  bwd {tb:7.1f} us ({bytes_b / tb / 1e6:5.2f} TB/s; merged {tbm:6.1f} us = {npix * D * 14 / tbm / 1e6:5.2f} TB/s) | ln fwd {tlf:6.1f} us  bwd {tlb:6.1f} us "
           f"({npix * Dh * 10 / tlb / 1e6:5.2f} TB/s)", flush=True)
