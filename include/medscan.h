@@ -334,6 +334,12 @@ int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const vo
  * only, no split-K.  bias (N) fp32 or NULL. */
 int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
                           void *C, int c_mode, int64_t ldc, int M, int N, int K, const float *bias, int relu, void *stream);
+/* Weight AND bias gradient of that 1x1 convolution in one launch (its autograd, MedMamba.py:525): dW (N, K) += dy^T x and
+ * dbias (N) += column sums of dy, for dy (M, N), x (M, K) row-major (lddy, ldx elements between rows); split-K inside the kernel
+ * (k_splits slices of the M tokens), fp32 atomics: zero dW and dbias first.  The column sums ride on the matrix cores (one MFMA per
+ * dy fragment against an all-ones fragment) instead of a reduction pass of their own over dy. */
+int ms_gemm_bf16_wgrad_bias(const void *dy, int dy_is_f32, int64_t lddy, const void *x, int x_is_f32, int64_t ldx, float *dW, int64_t lddw,
+                            float *dbias, int N, int K, int M, int k_splits, void *stream);
 
 /* ---- bf16 working copies of the fp32 master weights, all in one launch ---------------------------------------------------
  * What torch.autocast does with one `_to_copy` launch per weight per forward (plus a layout copy per convolution weight on the

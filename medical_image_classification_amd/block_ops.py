@@ -391,8 +391,14 @@ class _Conv1x1ReLU(torch.autograd.Function):
         if dz.dtype not in (torch.bfloat16, torch.float32) or not dz.is_contiguous():
             dz = dz.contiguous().float()
         dx = gemm(dz, w2, b_trans=True, out_dtype=xm.dtype) if ctx.needs_input_grad[0] else None
-        dw = weight_grad(dz, xm) if ctx.needs_input_grad[1] else None
-        db = dz.sum(dim=0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        from .gemm_ops import wgrad_bias_ok
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db and wgrad_bias_ok(dz, xm):
+            db = arena.zeros((Co,), dz.device)                # the column sums of dz ride on the weight-gradient launch
+            dw = weight_grad(dz, xm, dbias=db)
+        else:
+            dw = weight_grad(dz, xm) if ctx.needs_input_grad[1] else None
+            db = dz.sum(dim=0, dtype=torch.float32) if want_db else None
         return (dx.view(B, H, W, C).permute(0, 3, 1, 2) if dx is not None else None,
                 dw.view(Co, C, 1, 1) if dw is not None else None, db, None)
 

@@ -80,6 +80,12 @@ int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda,
                                   (hipStream_t)stream);
 }
 
+int ms_gemm_bf16_wgrad_bias(const void *dy, int dy_is_f32, int64_t lddy, const void *x, int x_is_f32, int64_t ldx, float *dW, int64_t lddw,
+                            float *dbias, int N, int K, int M, int k_splits, void *stream) {
+    if (!dbias) return MS_ERR_NULL;
+    return ms::gemm_bf16_dispatch(dy, dy_is_f32, 1, lddy, x, x_is_f32, 1, ldx, dW, 2, lddw, N, K, M, k_splits, dbias, 0, (hipStream_t)stream);
+}
+
 int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream) {
     return ms::conv3x3_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, (hipStream_t)stream);
 }

@@ -141,6 +141,14 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
     for (int a = 0; a < TNT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // CMODE 2 with `bias` set: `bias` is an OUTPUT -- rowsum[m] += sum_k Aop[m][k] (the bias gradient of a 1x1 convolution next to
+    // its weight gradient: Aop = dy^T, so the row sums are dy's column sums).  One more MFMA per A fragment against an all-ones
+    // fragment in the first column block's workgroups, instead of a separate reduction pass over dy.
+    const bool row_sums = CMODE == 2 && bias != nullptr && blockIdx.y == 0;
+    f32x4 accs[CMODE == 2 ? MT : 1];
+#pragma unroll
+    for (int b = 0; b < (CMODE == 2 ? MT : 1); ++b) accs[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     // register staging two k-steps deep: the loads of steps k+1 and k+2 are in flight while step k is multiplied (with
     // K <= 128 -- in_proj / x_proj of the first stages -- the whole operand is requested before the first MFMA)
@@ -168,6 +176,12 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
             bf16x8 fa[MT];
 #pragma unroll
             for (int b = 0; b < MT; ++b) fa[b] = TA::frag(sA, w * MT + b, ks, lane);
+            if constexpr (CMODE == 2) {
+                if (row_sums) {
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) accs[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[b], accs[b], 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < TNT; ++a) {
                 const bf16x8 fb = TB::frag(sB, a, ks, lane);
@@ -183,6 +197,15 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
         if (k0 + kBK < kend) step(ta[1], tb[1], k0 + kBK);
     }
     if constexpr (CMODE >= 2) {
+        if constexpr (CMODE == 2) {
+            if (row_sums && fq == 0) {                   // D[i][j] = sum_k Aop[m0 + .. + j][k] in every row i: lane (fr, 0) holds column fr
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    const int m = m0 + w * (16 * MT) + b * 16 + fr;
+                    if (m < M) atomicAdd(const_cast<float *>(bias) + m, accs[b][0]);
+                }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < MT; ++b)
 #pragma unroll
@@ -306,7 +329,8 @@ void gemm_debug_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
                        int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream) {
     if (!A || !B || !C) return MS_ERR_NULL;
-    if ((bias || relu) && c_mode >= 2) return MS_ERR_SHAPE;          // the epilogue belongs to the store modes
+    // the epilogue belongs to the store modes; in c_mode 2 `bias` is the row-sum OUTPUT of the weight-gradient form (see the kernel)
+    if ((relu && c_mode >= 2) || (bias && c_mode == 3) || (bias && c_mode == 2 && !(a_trans && b_trans))) return MS_ERR_SHAPE;
     if (M <= 0 || N <= 0 || K <= 0 || k_splits < 1 || c_mode < 0 || c_mode > 3) return MS_ERR_SHAPE;
     if (k_splits > 1 && c_mode < 2) return MS_ERR_SHAPE;
     if (!combo_built(a_f32, b_f32, a_trans, b_trans, c_mode)) return MS_ERR_UNSUPPORTED;

@@ -38,12 +38,28 @@ def _blocks(rows, cols):
     return -(-rows // 128) * -(-cols // bn)
 
 
-def weight_grad(dy, x, out=None):
-    """dW (N, K) (+)= dy^T @ x for dy (M, N), x (M, K): split-K inside the kernel, the taller of (N, K) on the row side."""
+def wgrad_bias_ok(dy, x):
+    return dy.shape[1] >= x.shape[1]
+
+
+def weight_grad(dy, x, out=None, dbias=None):
+    """dW (N, K) (+)= dy^T @ x for dy (M, N), x (M, K): split-K inside the kernel, the taller of (N, K) on the row side.
+    dbias (N,) fp32, zero-initialised: also receives dy's column sums from the same launch (ms_gemm_bf16_wgrad_bias; only in the
+    orientation with dy on the row side, N >= K -- the caller checks `wgrad_bias_ok`)."""
     N, K = dy.shape[1], x.shape[1]
     M = dy.shape[0]
     if out is None:
         out = arena.zeros((N, K), dy.device)
+    if dbias is not None:
+        if not wgrad_bias_ok(dy, x):
+            raise RuntimeError("ms_gemm_bf16_wgrad_bias: needs N >= K")
+        _lib.require_cuda(dy, x)
+        with _lib.on_device(dy.device):
+            _lib.check(_lib.lib().ms_gemm_bf16_wgrad_bias(dy.data_ptr(), _is_f32(dy), dy.stride(0), x.data_ptr(), _is_f32(x), x.stride(0),
+                                                          out.data_ptr(), out.stride(0), dbias.data_ptr(), N, K, M,
+                                                          _k_splits(M, _blocks(N, K), N * K), _lib.current_stream_ptr(dy.device)),
+                       "ms_gemm_bf16_wgrad_bias")
+        return out
     if N >= K:
         return gemm(dy, x, a_trans=True, b_trans=True, out=out, accumulate=True, k_splits=_k_splits(M, _blocks(N, K), N * K))
     # (K x N) orientation, accumulated into the transposed output

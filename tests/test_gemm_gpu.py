@@ -118,3 +118,27 @@ def test_weight_grad_orientation(shape):
     dw = weight_grad(dy, x)
     ref = _round(dy).t() @ _round(x)
     np.testing.assert_allclose(dw.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(200704 // 8, 48, 48), (3136, 384, 384), (777, 136, 24), (130, 96, 96), (64 * 49, 192, 64)])
+@pytest.mark.parametrize("dy_f32", [False, True])
+def test_weight_gradient_with_bias_gradient_in_one_launch(cfg, dy_f32):
+    """ms_gemm_bf16_wgrad_bias: dW (N, K) += dy^T x and dbias (N) += column sums of dy (one more MFMA per dy fragment against an
+    all-ones fragment) vs float64 products of the bf16-rounded operands; ragged M / N / K, several k-slices."""
+    from medical_image_classification_amd.gemm_ops import weight_grad
+    M, N, K = cfg
+    torch.manual_seed(M + N)
+    dy = torch.randn(M, N, device=dev())
+    x = torch.randn(M, K, device=dev()).to(torch.bfloat16)
+    if not dy_f32:
+        dy = dy.to(torch.bfloat16)
+    dyr, xr = dy.to(torch.bfloat16).double(), x.double()
+    db = torch.zeros(N, device=dev())
+    dw = weight_grad(dy, x, dbias=db)
+    want_w, want_b = dyr.t() @ xr, dyr.sum(0)
+    np.testing.assert_allclose(dw.cpu().numpy(), want_w.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(want_w.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), want_b.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(want_b.abs().max()))
+    # accumulating: a second call doubles both
+    weight_grad(dy, x, out=dw, dbias=db)
+    np.testing.assert_allclose(db.cpu().numpy(), 2 * want_b.cpu().numpy(), rtol=1e-4, atol=2e-4 * float(want_b.abs().max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), 2 * want_w.cpu().numpy(), rtol=1e-4, atol=2e-4 * float(want_w.abs().max()))
