@@ -365,6 +365,12 @@ typedef struct MsCastDesc {
 #define MS_CAST_TILE_MAX_TAPS 9
 int ms_cast_bf16_multi(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, void *stream);
 
+/* im2col of the patch embedding `nn.Conv2d(in_chans, embed_dim, kernel_size=4, stride=4)` (MedMamba.py:146-169): x (batch, C, H, W)
+ * fp32 contiguous (16-byte aligned; H, W multiples of 4) -> out (batch * H/4 * W/4, C * 16) bf16 rows, row = patch (b, h/4, w/4),
+ * column = c * 16 + i * 4 + j = the order of `weight.view(embed_dim, -1)`.  The convolution is then ms_gemm_bf16_bias_act on these
+ * rows and its weight / bias gradient ms_gemm_bf16_wgrad_bias. */
+int ms_patchify4_bf16(const float *x, void *out, int batch, int C, int H, int W, void *stream);
+
 /* ---- `optimizer.step()` of the training loop: Adam over all parameters in one launch (/root/reference/train.py:62,76:
  * `optim.Adam(net.parameters(), lr=0.0001)`: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) ---------------------------
  *   desc   (device memory) one entry per parameter tensor: fp32 parameter, exp_avg, exp_avg_sq and the element count

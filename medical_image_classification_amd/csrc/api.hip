@@ -44,6 +44,7 @@ int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scra
                            int Ci, int Co, hipStream_t s);
 int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
 int cast_bf16_multi_dispatch(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, hipStream_t s);
+int patchify4_bf16_dispatch(const float *x, void *out, int batch, int C, int H, int W, hipStream_t s);
 int adam_multi_dispatch(const MsAdamDesc *desc, const int32_t *blocks, int n_blocks, const void *const *grads, int n_tensors,
                         float step_size, float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps,
                         hipStream_t s);
@@ -103,6 +104,10 @@ int ms_debug_gemm_tile(int bm, int bn) { ms::gemm_debug_tile(bm, bn); return MS_
 
 int ms_cast_bf16_multi(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, void *stream) {
     return ms::cast_bf16_multi_dispatch(desc, blocks, n_blocks, (hipStream_t)stream);
+}
+
+int ms_patchify4_bf16(const float *x, void *out, int batch, int C, int H, int W, void *stream) {
+    return ms::patchify4_bf16_dispatch(x, out, batch, C, H, W, (hipStream_t)stream);
 }
 
 int ms_adam_multi(const MsAdamDesc *desc, const int32_t *blocks, int n_blocks, const void *const *grads, int n_tensors,

@@ -79,6 +79,42 @@ cast_bf16_multi_kernel(const MsCastDesc *__restrict__ desc, const int2 *__restri
     }
 }
 
+// Non-overlapping 4 x 4 patches of an NCHW fp32 image batch as bf16 rows [patch][c * 16 + i * 4 + j] -- the im2col of the patch
+// embedding `nn.Conv2d(in_chans, embed_dim, 4, stride 4)` (MedMamba.py:146-169), whose product is then ONE GEMM on ms_gemm_bf16
+// (torch ran a layout copy of the images, MIOpen's implicit-GEMM kernel with five transposes around it, a cast of the output and
+// a reduction for the bias gradient: ~0.35 ms per step).  One thread = one 4-float row of a patch: 16-byte loads that are
+// consecutive along the image row, 8-byte stores.
+__global__ void __launch_bounds__(256)
+patchify4_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ out, int C, int H, int W, int64_t n_rows) {
+    const int pw_n = W / 4, ph_n = H / 4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n_rows; t += (int64_t)gridDim.x * 256) {
+        // t = (((b * ph_n + ph) * C + c) * 4 + i) * pw_n + pw : pw fastest (coalesced reads along the image row)
+        const int pw = (int)(t % pw_n);
+        int64_t r = t / pw_n;
+        const int i = (int)(r & 3); r >>= 2;
+        const int c = (int)(r % C); r /= C;
+        const int ph = (int)(r % ph_n);
+        const int64_t b = r / ph_n;
+        const float4 v = *reinterpret_cast<const float4 *>(x + ((b * C + c) * H + ph * 4 + i) * (int64_t)W + pw * 4);
+        uint2 o;
+        o.x = (unsigned)to_bf16(v.x) | ((unsigned)to_bf16(v.y) << 16);
+        o.y = (unsigned)to_bf16(v.z) | ((unsigned)to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(out + ((b * ph_n + ph) * pw_n + pw) * (int64_t)(C * 16) + c * 16 + i * 4) = o;
+    }
+}
+
+int patchify4_bf16_dispatch(const float *x, void *out, int batch, int C, int H, int W, hipStream_t s) {
+    if (!x || !out) return MS_ERR_NULL;
+    if (batch < 0 || C <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 4 != 0) return MS_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return MS_ERR_STRIDE;
+    const int64_t n_rows = (int64_t)batch * C * H * (W / 4);
+    if (n_rows == 0) return MS_OK;
+    const int64_t blocks = (n_rows + 255) / 256;
+    hipLaunchKernelGGL(patchify4_bf16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, x, (unsigned short *)out, C, H, W,
+                       n_rows);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
 int cast_bf16_multi_dispatch(const MsCastDesc *desc, const int32_t *blocks, int n_blocks, hipStream_t s) {
     if (n_blocks < 0) return MS_ERR_SHAPE;
     if (n_blocks == 0) return MS_OK;

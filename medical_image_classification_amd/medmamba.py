@@ -256,8 +256,56 @@ class PatchEmbed2D(nn.Module):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
-        x = self.proj(x).permute(0, 2, 3, 1)
+        if _patch_embed_gemm_ok(self.proj, x):
+            x = _PatchEmbedGemm.apply(x, self.proj.weight, self.proj.bias)              # (B, H/4, W/4, E) fp32, already token-major
+        else:
+            x = self.proj(x).permute(0, 2, 3, 1)
         return x if self.norm is None else _norm_rows(self.norm, x, out_bf16=False)
+
+
+def _patch_embed_gemm_ok(conv, x):
+    """4 x 4 / stride 4 patch embedding of an fp32 NCHW image batch that needs no gradient, under bf16 autocast: im2col
+    (ms_patchify4_bf16) + one GEMM with the bias in its epilogue; anything else runs the convolution itself."""
+    from .ss2d_ops import _MFMA_GEMM
+    return (BLOCK_FUSED and _MFMA_GEMM and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and not x.requires_grad
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and tuple(conv.kernel_size) == (4, 4) and tuple(conv.stride) == (4, 4) and tuple(conv.padding) == (0, 0)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is not None and conv.weight.dtype == torch.float32
+            and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and (conv.in_channels * 16) % 8 == 0 and x.data_ptr() % 16 == 0
+            and conv.out_channels >= conv.in_channels * 16)
+
+
+class _PatchEmbedGemm(torch.autograd.Function):
+    """`proj(x).permute(0, 2, 3, 1)` of PatchEmbed2D (MedMamba.py:160-165) as patches @ W^T + b on ms_gemm_bf16 (fp32 out, which is
+    what the LayerNorm behind it reads); backward: weight and bias gradient from one launch (ms_gemm_bf16_wgrad_bias)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .gemm_ops import gemm
+        B, C, H, W = x.shape
+        E = weight.shape[0]
+        M, K = B * (H // 4) * (W // 4), C * 16
+        patches = torch.empty((M, K), device=x.device, dtype=torch.bfloat16)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().ms_patchify4_bf16(x.data_ptr(), patches.data_ptr(), B, C, H, W, _lib.current_stream_ptr(x.device)),
+                       "ms_patchify4_bf16")
+        with torch.autocast(device_type="cuda", enabled=False):
+            y = gemm(patches, shadow.bf16(weight).view(E, K), out_dtype=torch.float32, bias=bias.detach().float())
+        ctx.save_for_backward(patches)
+        ctx.wshape, ctx.wdtype, ctx.bdtype = weight.shape, weight.dtype, bias.dtype
+        return y.view(B, H // 4, W // 4, E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import arena
+        from .gemm_ops import _rows, weight_grad
+        (patches,) = ctx.saved_tensors
+        shadow.invalidate(patches.device)
+        E = ctx.wshape[0]
+        dym = _rows(dy)
+        db = arena.zeros((E,), dym.device)
+        dw = weight_grad(dym, patches, dbias=db)
+        return None, dw.view(ctx.wshape).to(ctx.wdtype), db.to(ctx.bdtype)
 
 
 class _GatherTaps(torch.autograd.Function):

@@ -389,3 +389,36 @@ def test_ms_adam_matches_torch_adam_and_shares_its_state_dict():
     oc.param_groups[0]["params"][0].grad = torch.ones(5, device=dev())
     oc.step()
     assert float(oc.state_dict()["state"][0]["step"]) == 1.0
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 224, 224, 96), (3, 3, 32, 20, 48), (1, 4, 8, 8, 64)])
+def test_patch_embedding_as_im2col_gemm(cfg):
+    """PatchEmbed2D's 4 x 4 / stride 4 convolution under bf16 autocast = ms_patchify4_bf16 + ms_gemm_bf16_bias_act, its weight / bias
+    gradient ms_gemm_bf16_wgrad_bias: against F.conv2d in fp32 on the bf16-rounded operands (output, dW, db); the im2col itself
+    bit-exact against the view / permute formulation."""
+    from medical_image_classification_amd import _lib
+    from medical_image_classification_amd.medmamba import PatchEmbed2D, _patch_embed_gemm_ok
+    B, C, H, W, E = cfg
+    torch.manual_seed(E)
+    pe = PatchEmbed2D(patch_size=4, in_chans=C, embed_dim=E, norm_layer=None).to(dev())
+    x = torch.randn(B, C, H, W, device=dev())
+    patches = torch.empty(B * (H // 4) * (W // 4), C * 16, device=dev(), dtype=torch.bfloat16)
+    _lib.check(_lib.lib().ms_patchify4_bf16(x.data_ptr(), patches.data_ptr(), B, C, H, W, _lib.current_stream_ptr(dev())), "patchify")
+    want = x.view(B, C, H // 4, 4, W // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(-1, C * 16).to(torch.bfloat16)
+    assert torch.equal(patches, want)
+    g = torch.randn(B, H // 4, W // 4, E, device=dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert _patch_embed_gemm_ok(pe.proj, x)
+        y = pe(x)
+    assert y.dtype == torch.float32 and y.shape == (B, H // 4, W // 4, E)
+    dw, db = torch.autograd.grad(y, (pe.proj.weight, pe.proj.bias), g)
+    wr = pe.proj.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    br = pe.proj.bias.detach().clone().requires_grad_()
+    yr = F.conv2d(x.to(torch.bfloat16).float(), wr, br, stride=4).permute(0, 2, 3, 1)
+    dwr, dbr = torch.autograd.grad(yr, (wr, br), g.to(torch.bfloat16).float())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-4 * float(yr.detach().abs().max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), dwr.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(dwr.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), dbr.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(dbr.abs().max()))
+    # an input that needs a gradient keeps the convolution
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not _patch_embed_gemm_ok(pe.proj, x.clone().requires_grad_())
