@@ -8,6 +8,7 @@
 // Layout: x is (npix, C) with unit channel stride (the memory of an NCHW tensor in channels_last format).
 #include <hip/hip_runtime.h>
 #include "medscan.h"
+#include "ln_common.h"
 
 namespace ms {
 
@@ -97,18 +98,26 @@ bn_stats_kernel(const T *__restrict__ x, int64_t xps, float *__restrict__ part, 
 // Finalize blocks: 1024 threads = 16 channels x 64 row-slots; slot k adds partial rows k, k+64, ... (<= 16 loads in a
 // row per thread for 1024 partial rows -- a 4-slot version spent 59 us here, latency-bound), then an LDS tree over slots.
 constexpr int kFinCh = 16, kFinSlots = 64;
+// a wave holds 4 row-slots x 16 channels (lane = slot * 16 + channel): the slots of a wave are summed in registers
+// (v_permlane16_swap / v_permlane32_swap), the 16 waves through LDS -- two barriers instead of the ten of a 1024-thread LDS tree
+// (these kernels do microseconds of work 60 times per step: their time IS the barriers)
+__device__ __forceinline__ void bn_fin_combine(float &a, float &b, float (*red)[16][kFinCh]) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    a = across_groups<16>(a, lane); b = across_groups<16>(b, lane);
+    if (lane < kFinCh) { red[0][wv][lane] = a; red[1][wv][lane] = b; }
+    __syncthreads();
+    float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { sa += red[0][w][t % kFinCh]; sb += red[1][w][t % kFinCh]; }
+    a = sa; b = sb;
+}
 __device__ __forceinline__ void bn_sum_partials(const float *part, int nblk, int C, int c, bool cv, float &a, float &b) {
-    __shared__ float red[2][kFinCh * kFinSlots];
-    const int t = threadIdx.x, slot = t / kFinCh;
+    __shared__ float red[2][16][kFinCh];
+    const int slot = threadIdx.x / kFinCh;
     float sa = 0.0f, sb = 0.0f;
     if (cv) for (int k = slot; k < nblk; k += kFinSlots) { sa += part[(int64_t)k * 2 * C + c]; sb += part[(int64_t)k * 2 * C + C + c]; }
-    red[0][t] = sa; red[1][t] = sb;
-    __syncthreads();
-    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) {
-        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
-        __syncthreads();
-    }
-    a = red[0][t % kFinCh]; b = red[1][t % kFinCh];
+    bn_fin_combine(sa, sb, red);
+    a = sa; b = sb;
 }
 
 // finalize forward: Chan's merge of the per-block (n_b, mean_b, M2_b): mean = sum n_b mean_b / N, M2 = sum M2_b + n_b (mean_b - mean)^2;
@@ -117,7 +126,7 @@ __global__ void __launch_bounds__(kFinCh * kFinSlots)
 bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, int rpi, const float *__restrict__ shift,
                        float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt, float momentum, float eps,
                        float *__restrict__ save_mean, float *__restrict__ save_rstd, int64_t npix, int C) {
-    __shared__ float red[2][kFinCh * kFinSlots];
+    __shared__ float red[2][16][kFinCh];
     const int t = threadIdx.x, slot = t / kFinCh;
     const int c = blockIdx.x * kFinCh + t % kFinCh;
     const bool cv = c < C;
@@ -133,15 +142,10 @@ bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, int rpi, const 
         sa = fmaf(nb, dm, sa);
         sb += fmaf(nb * dm, dm, part[(int64_t)k * 2 * C + C + c]);
     }
-    red[0][t] = sa; red[1][t] = sb;
-    __syncthreads();
-    for (int s = kFinCh * kFinSlots / 2; s >= kFinCh; s >>= 1) {
-        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
-        __syncthreads();
-    }
-    const float s0 = red[0][t % kFinCh], mean = pvt + s0 / (float)npix;
+    bn_fin_combine(sa, sb, red);
+    const float s0 = sa, mean = pvt + s0 / (float)npix;
     if (cv && threadIdx.x < kFinCh) {
-        const float var = fmaxf((red[1][t] - s0 * s0 / (float)npix) / (float)npix, 0.0f);       // biased variance
+        const float var = fmaxf((sb - s0 * s0 / (float)npix) / (float)npix, 0.0f);       // biased variance
         const float sh = shift ? shift[c] : 0.0f;                      // the layer's logical input is x + shift
         save_mean[c] = mean; save_rstd[c] = rsqrtf(var + eps);
         const float unb = npix > 1 ? var * ((float)npix / (float)(npix - 1)) : var;
