@@ -8,6 +8,15 @@
 #include <hip/hip_runtime.h>
 #include "medscan.h"
 #include "ln_common.h"
+// the gate backward holds three inputs and two outputs per element: half the pixel slots of the other LayerNorm kernels keep it
+// under 100 VGPRs (5 waves per SIMD instead of 3)
+#ifndef MS_LNG_PB_DIV
+#define MS_LNG_PB_DIV 2
+#endif
+#define MS_LNG_SUB_DISPATCH(D, CALL)                                                                       \
+    if ((D) <= 64) { CALL(16, 1, 4 / MS_LNG_PB_DIV); } else if ((D) <= 128) { CALL(32, 1, 4 / MS_LNG_PB_DIV); }                           \
+    else if ((D) <= 256) { CALL(64, 1, 4 / MS_LNG_PB_DIV); } else if ((D) <= 512) { CALL(64, 2, 2 / MS_LNG_PB_DIV); }                     \
+    else if ((D) <= 768) { CALL(64, 3, 1); } else { CALL(64, 4, 1); }
 
 namespace ms {
 
@@ -258,7 +267,9 @@ __device__ __forceinline__ void gate_bwd_1(float y, float z, float go, float mea
     gv = dyh * gm;
 }
 
-template <int LPP, int V4, int PB, typename TZ, typename TG>
+// MERGED: y4 is the merged sum itself (dir_stride 0) -- its own instantiation, because the four-slab form keeps 4 x PB x V4 more
+// 16-byte loads alive: 156 VGPRs (3 waves per SIMD) against the merged form's ~100
+template <int LPP, int V4, int PB, bool MERGED, typename TZ, typename TG>
 __global__ void __launch_bounds__(256)
 ln_gate_bwd_sub_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__restrict__ z, int64_t zps,
                        const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -288,7 +299,7 @@ ln_gate_bwd_sub_kernel(const float *__restrict__ y4, int64_t sk, const TZ *__res
             for (int j = 0; j < V4; ++j) {
                 const int c = 4 * (lip + LPP * j);
                 const bool in = c < D;
-                y[q][j] = in ? merge4(y4 + pix * D, sk, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y[q][j] = in ? (MERGED ? ld4f(y4 + pix * D + c) : merge4(y4 + pix * D, sk, c)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 zz[q][j] = in ? ld4f(z + pix * zps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 g[q][j] = in ? ld4f(dout + pix * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 s1[q] += sum4(y[q][j]);
@@ -412,9 +423,11 @@ static int launch_bwd(const float *y4, int64_t sk, const void *z, int64_t zps, c
         const int64_t cap2 = npix >= 131072 ? 2048 : npix >= 8192 ? 512 : 256;
 #define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                      \
         const int64_t nb = (npix + per - 1) / per;                                                                         \
-        hipLaunchKernelGGL((ln_gate_bwd_sub_kernel<L, V, P, TZ, TG>), dim3((unsigned)(nb < cap2 ? nb : cap2)), dim3(256), 0, s, y4, sk,    \
+        if (sk == 0) hipLaunchKernelGGL((ln_gate_bwd_sub_kernel<L, V, P, true, TZ, TG>), dim3((unsigned)(nb < cap2 ? nb : cap2)), dim3(256), 0, s, y4, sk, \
+                           (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix, dzps);             \
+        else hipLaunchKernelGGL((ln_gate_bwd_sub_kernel<L, V, P, false, TZ, TG>), dim3((unsigned)(nb < cap2 ? nb : cap2)), dim3(256), 0, s, y4, sk, \
                            (const TZ *)z, zps, gamma, beta, eps, (const TG *)dout, dy, (TZ *)dz, dgamma, dbeta, D, npix, dzps); } while (0)
-        MS_LN_SUB_DISPATCH(D, MS_S)
+        MS_LNG_SUB_DISPATCH(D, MS_S)
 #undef MS_S
         return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
     }
