@@ -26,8 +26,20 @@ dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, c
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int d = dbase + lane + 64 * j;
+        if (R == RP && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+            // a channel's R weights are contiguous: RP / 4 16-byte loads instead of RP scalar ones (the prologue, not the pixels, was
+            // this kernel's time on small maps: 48 scattered loads per lane for 16 pixels of work at stage 3)
+            const float4 *wr = reinterpret_cast<const float4 *>(W + ((int64_t)k * D + min(d, D - 1)) * R);
 #pragma unroll
-        for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
+            for (int r4 = 0; r4 < RP / 4; ++r4) {
+                const float4 v = wr[r4];
+                w[j][4 * r4] = d < D ? v.x : 0.0f; w[j][4 * r4 + 1] = d < D ? v.y : 0.0f;
+                w[j][4 * r4 + 2] = d < D ? v.z : 0.0f; w[j][4 * r4 + 3] = d < D ? v.w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
+        }
     }
     float bv[VPT];                               // bias != NULL: delta' = softplus(delta + bias[k, d]) (MS_SCAN_DELTA_ACTIVATED)
 #pragma unroll
@@ -189,8 +201,20 @@ dtproj_fwd_s_kernel(const float *__restrict__ proj, const float *__restrict__ W,
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int d = dbase + lane + 64 * j;
+        if (R == RP && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+            // a channel's R weights are contiguous: RP / 4 16-byte loads instead of RP scalar ones (the prologue, not the pixels, was
+            // this kernel's time on small maps: 48 scattered loads per lane for 16 pixels of work at stage 3)
+            const float4 *wr = reinterpret_cast<const float4 *>(W + ((int64_t)k * D + min(d, D - 1)) * R);
 #pragma unroll
-        for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
+            for (int r4 = 0; r4 < RP / 4; ++r4) {
+                const float4 v = wr[r4];
+                w[j][4 * r4] = d < D ? v.x : 0.0f; w[j][4 * r4 + 1] = d < D ? v.y : 0.0f;
+                w[j][4 * r4 + 2] = d < D ? v.z : 0.0f; w[j][4 * r4 + 3] = d < D ? v.w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RP; ++r) w[j][r] = (d < D && r < R) ? W[((int64_t)k * D + d) * R + r] : 0.0f;
+        }
     }
     float bv[VPT];
 #pragma unroll
@@ -243,6 +267,8 @@ dtproj_dw_s_kernel(const float *__restrict__ ddelta, const float *__restrict__ p
         }
         __syncthreads();
         if (dbase < D) {
+            // (requesting the next group's rows one group ahead through a second register set was tried: the compiler then hoists the
+            // LDS reads of both groups -- 310 VGPRs, one wave per SIMD, 72 vs 66 us at stage 3)
 #pragma unroll 1
             for (int q0 = 0; q0 < 64; q0 += PF) {
                 float g[PF][VPT];
@@ -293,16 +319,37 @@ dtproj_dw_s_kernel(const float *__restrict__ ddelta, const float *__restrict__ p
 // dW[i] += sum over the nrows partial rows (dW arrives zero-filled like every accumulated output of this library)
 __global__ void __launch_bounds__(256)
 dtproj_dw_finalize_kernel(const float *__restrict__ part, float *__restrict__ dW, int n, int nrows) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int b = 0;
-    for (; b + 4 <= nrows; b += 4) {
-        a0 += part[(int64_t)b * n + i]; a1 += part[(int64_t)(b + 1) * n + i];
-        a2 += part[(int64_t)(b + 2) * n + i]; a3 += part[(int64_t)(b + 3) * n + i];
+    // 16 columns of 4 floats x 16 row slices per block, combined in LDS: a thread adds nrows / 16 rows instead of all of them
+    // (one thread per element walked ~100 rows in a dependent chain: 14.5 us for 7 MB)
+    __shared__ float4 red[16][16];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = (blockIdx.x * 16 + col) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        if (i + 4 <= n && (n & 3) == 0) {
+#pragma unroll 4
+            for (int b = sl; b < nrows; b += 16) {
+                const float4 v = *reinterpret_cast<const float4 *>(part + (int64_t)b * n + i);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        } else {
+            for (int b = sl; b < nrows; b += 16) {
+                const float *r = part + (int64_t)b * n + i;
+                a.x += r[0]; if (i + 1 < n) a.y += r[1]; if (i + 2 < n) a.z += r[2]; if (i + 3 < n) a.w += r[3];
+            }
+        }
     }
-    for (; b < nrows; ++b) a0 += part[(int64_t)b * n + i];
-    dW[i] += (a0 + a1) + (a2 + a3);
+    red[sl][col] = a;
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 8; s2 >= 1; s2 >>= 1) {
+        if (sl < s2) { float4 &m = red[sl][col]; const float4 o = red[sl + s2][col]; m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w; }
+        __syncthreads();
+    }
+    if (sl == 0 && i < n) {
+        const float4 t = red[0][col];
+        dW[i] += t.x; if (i + 1 < n) dW[i + 1] += t.y; if (i + 2 < n) dW[i + 2] += t.z; if (i + 3 < n) dW[i + 3] += t.w;
+    }
 }
 
 // ddts: workgroup = 4 waves = 4 slices of 64 channels over the SAME 64 pixels, lane = pixel: acc[r] += ddelta[p][d] * W[d][r] with
@@ -412,7 +459,9 @@ static int64_t dw_workers(int64_t npix, int ncbw) {
     // dWdt: workgroups of 4 channel slabs, persistent over 64-pixel tiles: about 8 workgroups per CU in total, at least 2 tiles each
     const int64_t ntiles = (npix + 63) / 64;
     int64_t bx = (2048 + 4 * ncbw - 1) / (4 * ncbw);
-    if (bx > (ntiles + 1) / 2) bx = (ntiles + 1) / 2;
+    // at least 2 tiles per workgroup -- unless that leaves the chip under-filled (7 x 7 maps: 49 tiles): then one tile each
+    const int64_t cap = ntiles * 4 * ncbw <= 1024 ? ntiles : (ntiles + 1) / 2;
+    if (bx > cap) bx = cap;
     return bx < 1 ? 1 : bx;
 }
 
@@ -439,7 +488,7 @@ static int launch_dt_s(bool bwd, const float *a, const float *proj, const float 
     const dim3 grid((unsigned)bx, (unsigned)(4 * ncbw));
     if (vpt == 2) hipLaunchKernelGGL((dtproj_dw_s_kernel<2, RP>), grid, dim3(256), 0, s, a, proj, o2, part, npix, D, R, C, ncbw);
     else          hipLaunchKernelGGL((dtproj_dw_s_kernel<1, RP>), grid, dim3(256), 0, s, a, proj, o2, part, npix, D, R, C, ncbw);
-    if (part) hipLaunchKernelGGL(dtproj_dw_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, o2, n, (int)bx);
+    if (part) hipLaunchKernelGGL(dtproj_dw_finalize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, o2, n, (int)bx);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
