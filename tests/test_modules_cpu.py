@@ -130,3 +130,24 @@ def test_vssm_restatement_matches_reference():
             ref = g[k]
             np.testing.assert_allclose(params[k[5:]].grad.numpy(), ref, rtol=5e-3,
                                        atol=5e-4 * max(1e-3, np.abs(ref).max()), err_msg=k)
+
+
+def test_ms_adam_on_cpu_parameters_is_torch_adam():
+    """adam.MsAdam is a torch.optim.Adam: parameters its one-launch kernel does not serve (CPU tensors here) take torch's own step,
+    bit for bit, and the state_dict is torch's."""
+    import torch
+    from medical_image_classification_amd.adam import MsAdam
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = MsAdam(a, lr=1e-2), torch.optim.Adam(b, lr=1e-2)
+    for step in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys() and float(sa["state"][0]["step"]) == 3.0
+    assert sa["param_groups"][0]["lr"] == sb["param_groups"][0]["lr"]
