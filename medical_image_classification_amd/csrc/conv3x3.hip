@@ -156,10 +156,13 @@ int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int 
     if (batch == 0) return MS_OK;
     const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH;
     const int tiles_per_img = tiles_w * tiles_h;
-    const int cb = 48;                                       // output channels per workgroup
+    // output channels per workgroup: 48 (MedMamba-T's 48 / 96 / 192 / 384), or 64 where that divides the count and 48 does not
+    // (MedMamba-B's 64 / 128 / 256 / 512: 64 = 48 + 16 would run a second, three-quarters empty block)
+    const int cb = (Co % 64 == 0 && Co % 48 != 0) ? 64 : 48;
     const dim3 grid((unsigned)(batch * tiles_per_img), (unsigned)((Co + cb - 1) / cb));
     using bf = unsigned short;
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<3>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img);
+    if (cb == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<4>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img);
+    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<3>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

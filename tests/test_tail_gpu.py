@@ -100,7 +100,7 @@ def test_conv_with_cached_weight_matches_autocast_conv():
     np.testing.assert_allclose(dwa.cpu().numpy(), dwb.cpu().numpy(), rtol=1e-2, atol=2e-2 * float(dwb.abs().max()))
 
 
-@pytest.mark.parametrize("cfg", [(2, 48, 56, 56), (3, 96, 28, 28), (2, 192, 14, 14), (1, 384, 7, 7), (2, 64, 9, 21), (1, 16, 1, 1), (2, 48, 17, 5)])
+@pytest.mark.parametrize("cfg", [(2, 48, 56, 56), (3, 96, 28, 28), (2, 192, 14, 14), (1, 384, 7, 7), (2, 64, 9, 21), (1, 128, 16, 16), (1, 256, 8, 9), (1, 16, 1, 1), (2, 48, 17, 5)])
 def test_direct_conv3x3_forward_and_input_gradient_vs_fp32(cfg):
     """ms_conv3x3_nhwc_bf16 (csrc/conv3x3.hip) and its input-gradient form (the same kernel on dy with the flipped / transposed
     weight copy) against fp32 torch on the bf16-rounded operands, at the conv-branch shapes and ragged ones (tile edges)."""
