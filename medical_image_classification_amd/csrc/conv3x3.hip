@@ -50,41 +50,53 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
         for (int n = 0; n < NB; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const unsigned short *xi = x + (int64_t)img * H * W * Ci;
-    constexpr int kNX = (kHH * kHW * (kKS / 8) + 255) / 256;            // 16-byte pieces per thread: halo (3) ...
+    constexpr int kNX = ((kHH * kHW + 15) / 16 * 64 + 255) / 256;       // 16-byte pieces per thread: halo (3; rows padded to groups of 16) ...
     constexpr int kNW = (9 * NB * 16 * (kKS / 8) + 255) / 256;          // ... and weights (7 at NB = 3)
     uint4 rx[kNX], rw[kNW];
     // a slice holds 32 or 16 channels (Ci % 16 == 0): 4 or 2 pieces per pixel / weight row
+    // thread -> (pixel or weight row, 16-byte piece): within every 64 consecutive work items the ROW is the fast index (16 rows x 4
+    // pieces, or 32 x 2 for a 16-channel slice), so that the 16 lanes of an LDS write group hold the same piece of 16 consecutive
+    // rows -- 16 different bank quads at the 80-byte pitch.  (Pieces fastest put 4 consecutive rows into one group: rows 0 and 3
+    // overlap in 12 of 16 banks, and half of the kernel's LDS-active cycles were bank conflicts.)  A wave-level load still covers the
+    // same 16 rows x 64 bytes, so global coalescing does not change.
+    auto item = [&](int idx, int psh, int &row, int &pc) {
+        const int l = idx & 63, sh = 6 - psh;
+        row = ((idx >> 6) << sh) + (l & ((1 << sh) - 1));
+        pc = l >> sh;
+    };
     auto fetch = [&](int k0) {
-        const int psh = (Ci - k0 >= kKS) ? 2 : 1, pm = (1 << psh) - 1;
-        const int nx = (kHH * kHW) << psh, nw = (9 * NB * 16) << psh;
+        const int psh = (Ci - k0 >= kKS) ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
-            const int idx = tid + i * 256, pix = idx >> psh, pc = idx & pm;
+            int pix, pc;
+            item(tid + i * 256, psh, pix, pc);
             const int ph = pix / kHW, hh = h0 - 1 + ph, ww = w0 - 1 + pix - ph * kHW;
-            const bool ok = idx < nx && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const bool ok = pix < kHH * kHW && hh >= 0 && hh < H && ww >= 0 && ww < W;
             rx[i] = make_uint4(0, 0, 0, 0);
             if (ok) rx[i] = *reinterpret_cast<const uint4 *>(xi + ((int64_t)hh * W + ww) * Ci + k0 + pc * 8);
         }
 #pragma unroll
         for (int i = 0; i < kNW; ++i) {
-            const int idx = tid + i * 256, row = idx >> psh, pc = idx & pm;          // row = tap * (NB*16) + col
+            int row, pc;                                             // row = tap * (NB*16) + col
+            item(tid + i * 256, psh, row, pc);
             const int tap = row / (NB * 16), col = row - tap * (NB * 16);
             rw[i] = make_uint4(0, 0, 0, 0);
-            if (idx < nw && co0 + col < Co) rw[i] = *reinterpret_cast<const uint4 *>(w + ((int64_t)(co0 + col) * 9 + tap) * Ci + k0 + pc * 8);
+            if (row < 9 * NB * 16 && co0 + col < Co) rw[i] = *reinterpret_cast<const uint4 *>(w + ((int64_t)(co0 + col) * 9 + tap) * Ci + k0 + pc * 8);
         }
     };
     auto put = [&](int ks) {
-        const int psh = ks == kKS ? 2 : 1, pm = (1 << psh) - 1;
-        const int nx = (kHH * kHW) << psh, nw = (9 * NB * 16) << psh;
+        const int psh = ks == kKS ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < nx) *reinterpret_cast<uint4 *>(sX + (idx >> psh) * kXP + (idx & pm) * 8) = rx[i];
+            int pix, pc;
+            item(tid + i * 256, psh, pix, pc);
+            if (pix < kHH * kHW) *reinterpret_cast<uint4 *>(sX + pix * kXP + pc * 8) = rx[i];
         }
 #pragma unroll
         for (int i = 0; i < kNW; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < nw) *reinterpret_cast<uint4 *>(sW + (idx >> psh) * kWP + (idx & pm) * 8) = rw[i];
+            int row, pc;
+            item(tid + i * 256, psh, row, pc);
+            if (row < 9 * NB * 16) *reinterpret_cast<uint4 *>(sW + row * kWP + pc * 8) = rw[i];
         }
     };
     fetch(0);
