@@ -24,6 +24,15 @@ constexpr int kWP = kKS + 8;                     // weight row pitch (bf16)
 }
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+// MS_CONV_PF2 = 1: two slices of prefetch distance through a second register set (182 VGPRs: two workgroups per CU instead of
+// three).  Measured 34.6 / 29.8 / 26.0 / 41.8 us cold at stages 0-3 against 31.8 / 27.5 / 25.8 / 41.0 with one set at three
+// workgroups per CU: off.
+#ifndef MS_CONV_PF2
+#define MS_CONV_PF2 0
+#endif
+#ifndef MS_CONV_WAVES
+#define MS_CONV_WAVES 3                  // 49 KB of LDS: three workgroups per CU
+#endif
 
 // NB = output-channel tiles of 16 per workgroup (3: 48 channels).
 // Staging is software-pipelined through registers: ALL 16-byte loads of a channel slice (halo + weights: <= 10 per thread) are
@@ -32,7 +41,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // -- not the MFMAs, not LDS -- were the kernel's time.)  Slices of 32 channels use v_mfma_f32_16x16x32_bf16 (one ds_read_b128 per
 // fragment), a 16-channel tail slice the K = 16 form.
 template <int NB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 49 KB of LDS: three workgroups per CU
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_CONV_WAVES, MS_CONV_WAVES)))
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
                     int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img) {
     __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kXP];
@@ -52,7 +61,10 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
     const unsigned short *xi = x + (int64_t)img * H * W * Ci;
     constexpr int kNX = ((kHH * kHW + 15) / 16 * 64 + 255) / 256;       // 16-byte pieces per thread: halo (3; rows padded to groups of 16) ...
     constexpr int kNW = (9 * NB * 16 * (kKS / 8) + 255) / 256;          // ... and weights (7 at NB = 3)
-    uint4 rx[kNX], rw[kNW];
+    uint4 rxa[kNX], rwa[kNW];
+#if MS_CONV_PF2
+    uint4 rxb[kNX], rwb[kNW];
+#endif
     // a slice holds 32 or 16 channels (Ci % 16 == 0): 4 or 2 pieces per pixel / weight row
     // thread -> (pixel or weight row, 16-byte piece): within every 64 consecutive work items the ROW is the fast index (16 rows x 4
     // pieces, or 32 x 2 for a 16-channel slice), so that the 16 lanes of an LDS write group hold the same piece of 16 consecutive
@@ -64,7 +76,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
         row = ((idx >> 6) << sh) + (l & ((1 << sh) - 1));
         pc = l >> sh;
     };
-    auto fetch = [&](int k0) {
+    auto fetch = [&](uint4 (&rx)[kNX], uint4 (&rw)[kNW], int k0) {
         const int psh = (Ci - k0 >= kKS) ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
@@ -84,7 +96,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             if (row < 9 * NB * 16 && co0 + col < Co) rw[i] = *reinterpret_cast<const uint4 *>(w + ((int64_t)(co0 + col) * 9 + tap) * Ci + k0 + pc * 8);
         }
     };
-    auto put = [&](int ks) {
+    auto put = [&](const uint4 (&rx)[kNX], const uint4 (&rw)[kNW], int ks) {
         const int psh = ks == kKS ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
@@ -99,13 +111,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             if (row < 9 * NB * 16) *reinterpret_cast<uint4 *>(sW + row * kWP + pc * 8) = rw[i];
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < Ci; k0 += kKS) {
-        const int ks = min(kKS, Ci - k0);                       // channels in this slice: 32, or a 16-channel tail
-        __syncthreads();                                        // the previous slice's fragments have been read
-        put(ks);
-        __syncthreads();
-        if (k0 + kKS < Ci) fetch(k0 + kKS);                     // in flight during the products below
+    auto mac = [&](int ks) {
         if (ks == kKS) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -141,7 +147,37 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
                 }
             }
         }
+    };
+#if MS_CONV_PF2
+    // TWO slices of prefetch distance (two register sets): the waves of the one-set version were parked on s_waitcnt / barriers for
+    // half of their cycles -- a slice's loads could only be issued after the previous slice had been written to LDS
+    fetch(rxa, rwa, 0);
+    if (kKS < Ci) fetch(rxb, rwb, kKS);
+    for (int k0 = 0; k0 < Ci; k0 += 2 * kKS) {
+        __syncthreads();
+        put(rxa, rwa, min(kKS, Ci - k0));
+        __syncthreads();
+        if (k0 + 2 * kKS < Ci) fetch(rxa, rwa, k0 + 2 * kKS);
+        mac(min(kKS, Ci - k0));
+        if (k0 + kKS < Ci) {
+            __syncthreads();
+            put(rxb, rwb, min(kKS, Ci - k0 - kKS));
+            __syncthreads();
+            if (k0 + 3 * kKS < Ci) fetch(rxb, rwb, k0 + 3 * kKS);
+            mac(min(kKS, Ci - k0 - kKS));
+        }
     }
+#else
+    fetch(rxa, rwa, 0);
+    for (int k0 = 0; k0 < Ci; k0 += kKS) {
+        const int ks = min(kKS, Ci - k0);                       // channels in this slice: 32, or a 16-channel tail
+        __syncthreads();                                        // the previous slice's fragments have been read
+        put(rxa, rwa, ks);
+        __syncthreads();
+        if (k0 + kKS < Ci) fetch(rxa, rwa, k0 + kKS);           // in flight during the products below
+        mac(ks);
+    }
+#endif
     // D = B^T-major product: row index (4 * fq + r) = output channel within the tile, column fr = pixel
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
