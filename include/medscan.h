@@ -271,6 +271,15 @@ int ms_bn_relu_nhwc_bwd(const void *x, int x_is_bf16, int64_t x_pixel_stride, co
                         float *scratch, int64_t npix, int C, void *stream);
 int ms_bn_scratch_floats(int C);
 
+/* PatchMerging2D's tap gather + LayerNorm(4C) in one pass (MedMamba.py:196-205): x (batch, H, W, C) fp32 contiguous, H and W even,
+ * C % 4 == 0, 4C <= 1024; token (b, h2, w2) = the channels of pixels (2h2, 2w2), (2h2+1, 2w2), (2h2, 2w2+1), (2h2+1, 2w2+1) in that
+ * order; out (batch * H/2 * W/2, 4C) fp32 or bf16.  bwd: dx (batch, H, W, C) fp32 is WRITTEN (every input pixel belongs to exactly
+ * one token: the scatter is the same map); dgamma / dbeta (4C) are ACCUMULATED. */
+int ms_layernorm_taps_fwd(const float *x, const float *gamma, const float *beta, float eps, void *out, int out_is_bf16, int batch, int H,
+                          int W, int C, void *stream);
+int ms_layernorm_taps_bwd(const float *x, const float *gamma, float eps, const void *dout, int dout_is_bf16, float *dx, float *dgamma,
+                          float *dbeta, int batch, int H, int W, int C, void *stream);
+
 /* ---- delta projection of SS2D (the `dt_projs` einsum, MedMamba.py:400,403-405) -------------------------------------
  * proj   (npix, 4, row_width) fp32: the x_proj output rows [dts(R) | B(N) | C(N)] of every (pixel, direction)
  * Wdt    (4, D, R) fp32 = dt_projs_weight;  delta / ddelta (4, npix, D) fp32;  R <= 32

@@ -65,6 +65,54 @@ class _LayerNormRows(torch.autograd.Function):
         return dx, dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None
 
 
+class _LayerNormTaps(torch.autograd.Function):
+    """LayerNorm(4C) over the 2 x 2 tap concatenation of a (B, H, W, C) fp32 tensor: PatchMerging2D's gather and norm
+    (MedMamba.py:196-205) in ONE pass each way (ms_layernorm_taps_*: the gather is an addressing mode of the LayerNorm kernel, the
+    scatter of its dx store) instead of a permuting copy + LayerNorm forward and LayerNorm + permuting copy backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_bf16):
+        B, H, W, C = x.shape
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        out = torch.empty((B, H // 2, W // 2, 4 * C), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().ms_layernorm_taps_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), out.data_ptr(), int(out_bf16),
+                                                        B, H, W, C, _stream(x)), "ms_layernorm_taps_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.eps, ctx.wdtype, ctx.bdtype = float(eps), weight.dtype, bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        B, H, W, C = x.shape
+        if dout.dtype not in (torch.float32, torch.bfloat16):
+            dout = dout.float()
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dgb = arena.zeros((2, 4 * C), x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().ms_layernorm_taps_bwd(x.data_ptr(), w.data_ptr(), ctx.eps, dout.data_ptr(), int(dout.dtype == torch.bfloat16),
+                                                        dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), B, H, W, C, _stream(x)),
+                       "ms_layernorm_taps_bwd")
+        return dx, dgb[0].to(ctx.wdtype), dgb[1].to(ctx.bdtype), None, None
+
+
+def layernorm_taps_ok(x, norm):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+            and x.shape[3] % 4 == 0 and 4 * x.shape[3] <= 1024 and x.data_ptr() % 16 == 0 and type(norm) is torch.nn.LayerNorm
+            and norm.elementwise_affine and norm.bias is not None and tuple(norm.normalized_shape) == (4 * x.shape[3],))
+
+
+def layernorm_taps(x, norm, out_bf16=None):
+    """`norm(cat of the four 2 x 2 taps of x)` -> (B, H/2, W/2, 4C); out_bf16=None: bf16 under bf16 autocast."""
+    if out_bf16 is None:
+        out_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _LayerNormTaps.apply(x, norm.weight, norm.bias, norm.eps, bool(out_bf16))
+
+
 def layernorm_rows(x, weight, bias, eps, out_bf16=None):
     """LayerNorm over the last axis of a (.., D) fp32 tensor that may be a channel slice of a wider tensor.
     out_bf16=None: bf16 when CUDA autocast to bf16 is on (what the next linear would cast to), fp32 otherwise."""

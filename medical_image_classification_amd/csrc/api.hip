@@ -52,6 +52,10 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
                     int out_bf16, int64_t npix, int D, hipStream_t s);
 int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx,
                     float *dgamma, float *dbeta, int64_t npix, int D, hipStream_t s);
+int ln_taps_fwd_dispatch(const float *x, const float *gamma, const float *beta, float eps, void *out, int out_bf16, int batch, int H, int W,
+                         int C, hipStream_t s);
+int ln_taps_bwd_dispatch(const float *x, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx, float *dgamma,
+                         float *dbeta, int batch, int H, int W, int C, hipStream_t s);
 int dtproj_fwd_dispatch(const float *proj, const float *W, const float *bias, float *delta, int64_t npix, int D, int R, int C, hipStream_t s);
 int dtproj_bwd_dispatch(const float *ddelta, const float *proj, const float *W, float *dproj, float *dW, float *scratch,
                         int64_t scratch_floats, int64_t npix, int D, int R, int C, hipStream_t s);
@@ -224,6 +228,16 @@ int ms_layernorm_fwd(const float *x, int64_t x_pixel_stride, const float *gamma,
 int ms_layernorm_bwd(const float *x, int64_t x_pixel_stride, const float *gamma, float eps, const void *dout, int dout_is_bf16,
                      float *dx, float *dgamma, float *dbeta, int64_t npix, int D, void *stream) {
     return ms::ln_bwd_dispatch(x, x_pixel_stride, gamma, eps, dout, dout_is_bf16, dx, dgamma, dbeta, npix, D, (hipStream_t)stream);
+}
+
+int ms_layernorm_taps_fwd(const float *x, const float *gamma, const float *beta, float eps, void *out, int out_is_bf16, int batch, int H,
+                          int W, int C, void *stream) {
+    return ms::ln_taps_fwd_dispatch(x, gamma, beta, eps, out, out_is_bf16, batch, H, W, C, (hipStream_t)stream);
+}
+
+int ms_layernorm_taps_bwd(const float *x, const float *gamma, float eps, const void *dout, int dout_is_bf16, float *dx, float *dgamma,
+                          float *dbeta, int batch, int H, int W, int C, void *stream) {
+    return ms::ln_taps_bwd_dispatch(x, gamma, eps, dout, dout_is_bf16, dx, dgamma, dbeta, batch, H, W, C, (hipStream_t)stream);
 }
 
 int ms_dtproj_fwd(const float *proj, const float *Wdt, float *delta, int64_t npix, int D, int R, int row_width, void *stream) {

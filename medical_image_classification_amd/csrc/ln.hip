@@ -151,10 +151,32 @@ ln_bwd_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict_
 }
 
 // ---- sub-wave pixel groups, 16-byte accesses, VALU all-reduces (ln_common.h): the kernels every aligned call takes ------------
-template <int LPP, int V4, int PB, typename TO>
+// TAPS: the row of output token (b, h2, w2) is the concatenation of its 2 x 2 input pixels' channels in the order (0,0), (1,0), (0,1),
+// (1,1) -- PatchMerging2D's gather (MedMamba.py:196-200) as an addressing mode of the LayerNorm behind it (and of that LayerNorm's
+// dx store: every input pixel belongs to exactly one token, so the scatter is the same map), instead of a permuting copy each way.
+struct LnTaps { int h2n, w2n, cin; };
+template <bool TAPS>
+__device__ __forceinline__ int64_t ln_row_base(int64_t pix, int64_t xps, const LnTaps &tp, int64_t (&base)[4]) {
+    if constexpr (!TAPS) { base[0] = pix * xps; return 0; }
+    const int w2 = (int)(pix % tp.w2n);
+    const int64_t t = pix / tp.w2n;
+    const int h2 = (int)(t % tp.h2n);
+    const int64_t b = t / tp.h2n;
+    const int64_t row0 = (b * 2 * tp.h2n + 2 * h2) * (2 * tp.w2n) + 2 * w2;      // pixel (2 h2, 2 w2)
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) base[tap] = (row0 + (tap & 1) * (2 * tp.w2n) + (tap >> 1)) * tp.cin;
+    return 0;
+}
+template <bool TAPS>
+__device__ __forceinline__ int64_t ln_off(const int64_t (&base)[4], int c, const LnTaps &tp) {
+    if constexpr (!TAPS) return base[0] + c;
+    const int tap = c / tp.cin;
+    return base[tap] + (c - tap * tp.cin);
+}
+template <int LPP, int V4, int PB, typename TO, bool TAPS = false>
 __global__ void __launch_bounds__(256)
 ln_fwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict__ gamma, const float *__restrict__ beta,
-                  float eps, TO *__restrict__ out, int D, int64_t npix) {
+                  float eps, TO *__restrict__ out, int D, int64_t npix, LnTaps tp) {
     constexpr int PW = 64 / LPP;
     const int lane = threadIdx.x & 63, lip = lane % LPP, sub = lane / LPP;
     const int64_t p0 = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PB) * PW;
@@ -165,11 +187,13 @@ ln_fwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restr
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int64_t pix = min(p0 + q * PW + sub, npix - 1);
+        int64_t rb[4];
+        ln_row_base<TAPS>(pix, xps, tp, rb);
         s1[q] = 0.0f;
 #pragma unroll
         for (int j = 0; j < V4; ++j) {
             const int c = 4 * (lip + LPP * j);
-            v[q][j] = c < D ? ld4f(x + pix * xps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[q][j] = c < D ? ld4f(x + ln_off<TAPS>(rb, c, tp)) : make_float4(0.f, 0.f, 0.f, 0.f);
             s1[q] += sum4(v[q][j]);
         }
     }
@@ -205,11 +229,11 @@ ln_fwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restr
     }
 }
 
-template <int LPP, int V4, int PB, typename TG>
+template <int LPP, int V4, int PB, typename TG, bool TAPS = false>
 __global__ void __launch_bounds__(256)
 ln_bwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restrict__ gamma, float eps,
                   const TG *__restrict__ dout, float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                  int D, int64_t npix) {
+                  int D, int64_t npix, LnTaps tp) {
     constexpr int PW = 64 / LPP, NC = 4 * V4 * LPP;                     // channel slots of a group
     __shared__ __attribute__((aligned(16))) float red[4][2][NC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lip = lane % LPP, sub = lane / LPP;
@@ -229,12 +253,14 @@ ln_bwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restr
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int64_t pix = min(p0 + q * PW + sub, npix - 1);       // duplicates of the last pixel are computed, not stored
+            int64_t rb[4];
+            ln_row_base<TAPS>(pix, xps, tp, rb);
             s1[q] = 0.0f;
 #pragma unroll
             for (int j = 0; j < V4; ++j) {
                 const int c = 4 * (lip + LPP * j);
                 const bool in = c < D;
-                v[q][j] = in ? ld4f(x + pix * xps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[q][j] = in ? ld4f(x + ln_off<TAPS>(rb, c, tp)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 g[q][j] = in ? ld4f(dout + pix * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 s1[q] += sum4(v[q][j]);
             }
@@ -282,12 +308,14 @@ ln_bwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restr
         for (int q = 0; q < PB; ++q) {
             const int64_t pix = p0 + q * PW + sub;
             if (pix >= npix) continue;
+            int64_t rb[4];
+            ln_row_base<TAPS>(pix, (int64_t)D, tp, rb);                 // dx: (npix, D) rows, or scattered back to the input's pixels
 #pragma unroll
             for (int j = 0; j < V4; ++j) {
                 const int c = 4 * (lip + LPP * j);
                 if (c < D) {
                     const float4 vv = v[q][j], gg = g[q][j];
-                    st4f(dx + pix * D + c, make_float4(s2[q] * (gg.x - m1[q] - vv.x * m2[q]), s2[q] * (gg.y - m1[q] - vv.y * m2[q]),
+                    st4f(dx + ln_off<TAPS>(rb, c, tp), make_float4(s2[q] * (gg.x - m1[q] - vv.x * m2[q]), s2[q] * (gg.y - m1[q] - vv.y * m2[q]),
                                                        s2[q] * (gg.z - m1[q] - vv.z * m2[q]), s2[q] * (gg.w - m1[q] - vv.w * m2[q])));
                 }
             }
@@ -327,8 +355,8 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
     if (D % 4 == 0 && xps % 4 == 0 && ln_aligned(x, 16) && ln_aligned(gamma, 16) && ln_aligned(beta, 16) && ln_aligned(out, out_bf16 ? 8 : 16)) {
 #define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                           \
         const dim3 g((unsigned)((npix + per - 1) / per));                                                                       \
-        if (out_bf16) hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (unsigned short *)out, D, npix); \
-        else hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (float *)out, D, npix); } while (0)
+        if (out_bf16) hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (unsigned short *)out, D, npix, LnTaps{0, 0, 0}); \
+        else hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (float *)out, D, npix, LnTaps{0, 0, 0}); } while (0)
         MS_LN_SUB_DISPATCH(D, MS_S)
 #undef MS_S
         return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
@@ -359,8 +387,8 @@ int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, 
 #define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                           \
         const int64_t nb = (npix + per - 1) / per;                                                                              \
         const dim3 g((unsigned)(nb < cap2 ? nb : cap2));                                                                        \
-        if (dout_bf16) hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix); \
-        else hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix); } while (0)
+        if (dout_bf16) hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix, LnTaps{0, 0, 0}); \
+        else hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix, LnTaps{0, 0, 0}); } while (0)
         MS_LN_SUB_DISPATCH(D, MS_S)
 #undef MS_S
         return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
@@ -385,6 +413,45 @@ int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, 
 #undef MS_C
     }
 #undef MS_PB
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+// LayerNorm over the 2 x 2 tap concatenation of a (batch, H, W, C) fp32 tensor (PatchMerging2D, MedMamba.py:196-205)
+int ln_taps_fwd_dispatch(const float *x, const float *gamma, const float *beta, float eps, void *out, int out_bf16, int batch, int H, int W,
+                         int C, hipStream_t s) {
+    if (!x || !gamma || !beta || !out) return MS_ERR_NULL;
+    const int D = 4 * C;
+    if (batch < 0 || H <= 0 || W <= 0 || C <= 0 || H % 2 || W % 2 || C % 4 || D > 64 * kLnMaxVPT) return MS_ERR_SHAPE;
+    if (!ln_aligned(x, 16) || !ln_aligned(gamma, 16) || !ln_aligned(beta, 16) || !ln_aligned(out, out_bf16 ? 8 : 16)) return MS_ERR_STRIDE;
+    const int64_t npix = (int64_t)batch * (H / 2) * (W / 2);
+    if (npix == 0) return MS_OK;
+    const LnTaps tp{H / 2, W / 2, C};
+#define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                           \
+        const dim3 g((unsigned)((npix + per - 1) / per));                                                                       \
+        if (out_bf16) hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, unsigned short, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, beta, eps, (unsigned short *)out, D, npix, tp); \
+        else hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, float, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, beta, eps, (float *)out, D, npix, tp); } while (0)
+    MS_LN_SUB_DISPATCH(D, MS_S)
+#undef MS_S
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int ln_taps_bwd_dispatch(const float *x, const float *gamma, float eps, const void *dout, int dout_bf16, float *dx, float *dgamma,
+                         float *dbeta, int batch, int H, int W, int C, hipStream_t s) {
+    if (!x || !gamma || !dout || !dx || !dgamma || !dbeta) return MS_ERR_NULL;
+    const int D = 4 * C;
+    if (batch < 0 || H <= 0 || W <= 0 || C <= 0 || H % 2 || W % 2 || C % 4 || D > 64 * kLnMaxVPT) return MS_ERR_SHAPE;
+    if (!ln_aligned(x, 16) || !ln_aligned(gamma, 16) || !ln_aligned(dx, 16) || !ln_aligned(dout, dout_bf16 ? 8 : 16)) return MS_ERR_STRIDE;
+    const int64_t npix = (int64_t)batch * (H / 2) * (W / 2);
+    if (npix == 0) return MS_OK;
+    const LnTaps tp{H / 2, W / 2, C};
+    const int64_t cap2 = npix >= 32768 ? 512 : 256;
+#define MS_S(L, V, P) do { const int64_t per = 4ll * (P) * (64 / (L));                                                           \
+        const int64_t nb = (npix + per - 1) / per;                                                                              \
+        const dim3 g((unsigned)(nb < cap2 ? nb : cap2));                                                                        \
+        if (dout_bf16) hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, unsigned short, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix, tp); \
+        else hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, float, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix, tp); } while (0)
+    MS_LN_SUB_DISPATCH(D, MS_S)
+#undef MS_S
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

@@ -22,7 +22,7 @@ import torch.utils.checkpoint as checkpoint
 
 from . import _lib
 from . import shadow
-from .block_ops import BlockFrame, block_tail, conv_branch, layernorm_rows, split_halves
+from .block_ops import BlockFrame, block_tail, conv_branch, layernorm_rows, layernorm_taps, layernorm_taps_ok, split_halves
 from .selective_scan_interface import selective_scan_fn
 from .ss2d_fused import dwconv3x3_silu_nhwc, ss2d_core, ss2d_core_norm_gate, ss2d_inner
 from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_splitk
@@ -341,6 +341,9 @@ class PatchMerging2D(nn.Module):
         if (W % 2 != 0) or (H % 2 != 0):
             print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
         # order of the four taps as in the reference: (0,0), (1,0), (0,1), (1,1)
+        if BLOCK_FUSED and layernorm_taps_ok(x, self.norm):
+            # gather + LayerNorm in one pass each way (the gather is an addressing mode of the LayerNorm kernel)
+            return linear_splitk(layernorm_taps(x, self.norm), self.reduction.weight, out_fp32=True)
         if H % 2 == 0 and W % 2 == 0 and x.is_contiguous():
             x = _GatherTaps.apply(x)
         else:

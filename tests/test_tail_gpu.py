@@ -422,3 +422,34 @@ def test_patch_embedding_as_im2col_gemm(cfg):
     # an input that needs a gradient keeps the convolution
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert not _patch_embed_gemm_ok(pe.proj, x.clone().requires_grad_())
+
+
+@pytest.mark.parametrize("cfg", [(2, 56, 56, 96), (3, 6, 10, 12), (1, 14, 14, 192), (2, 4, 2, 256)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_patch_merging_gather_inside_the_layernorm(cfg, bf16):
+    """ms_layernorm_taps_fwd/bwd (PatchMerging2D's 2 x 2 tap gather as an addressing mode of its LayerNorm, the scatter of the dx
+    store) against F.layer_norm of the explicit concatenation in float64: output, dx, dgamma, dbeta."""
+    from medical_image_classification_amd.block_ops import layernorm_taps, layernorm_taps_ok
+    B, H, W, C = cfg
+    torch.manual_seed(C)
+    x = (torch.randn(B, H, W, C, device=dev()) * 2 + 0.3).requires_grad_()
+    norm = nn.LayerNorm(4 * C).to(dev())
+    with torch.no_grad():
+        norm.weight.normal_(); norm.bias.normal_()
+    assert layernorm_taps_ok(x, norm)
+    y = layernorm_taps(x, norm, out_bf16=bf16)
+    assert y.shape == (B, H // 2, W // 2, 4 * C) and y.dtype == (torch.bfloat16 if bf16 else torch.float32)
+    g = torch.randn(B, H // 2, W // 2, 4 * C, device=dev())
+    if bf16:
+        g = g.to(torch.bfloat16)
+    dx, dw, db = torch.autograd.grad(y, (x, norm.weight, norm.bias), g)
+    xr = x.detach().double().requires_grad_()
+    wr, br = norm.weight.detach().double().requires_grad_(), norm.bias.detach().double().requires_grad_()
+    taps = torch.cat([xr[:, i::2, j::2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))], dim=-1)
+    yr = F.layer_norm(taps, (4 * C,), wr, br, norm.eps)
+    dxr, dwr, dbr = torch.autograd.grad(yr, (xr, wr, br), g.double())
+    tol = 2e-2 if bf16 else 1e-4
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().float().cpu().numpy(), rtol=tol, atol=tol * float(yr.detach().abs().max()))
+    np.testing.assert_allclose(dx.cpu().numpy(), dxr.float().cpu().numpy(), rtol=1e-3, atol=1e-4 * float(dxr.abs().max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), dwr.float().cpu().numpy(), rtol=1e-3, atol=1e-4 * float(dwr.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), dbr.float().cpu().numpy(), rtol=1e-3, atol=1e-4 * float(dbr.abs().max()))
