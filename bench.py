@@ -2,7 +2,8 @@
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, which sets
+   RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, or bare -- then bench.py starts its own N rank processes, self_launch())
 
 A "step" = one full training step (forward + backward + Adam) of MedMamba-T (depths [2,2,4,2], dims
 [96,192,384,768], d_state 16) on one synthetic batch of 64 3x224x224 images per GPU (BASELINE.json
@@ -59,6 +60,9 @@ def parse():
                          "per-process algorithm picks spread the step time from 26.9 to 33.5 ms")
     ap.add_argument("--no-miopen-find", dest="miopen_find", action="store_false", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal: rendezvous + one all-reduce + the JSON line, no model and no GPU needed "
+                         "(MEDSCAN_DIST_BACKEND=gloo on a CPU-only host)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -148,10 +152,88 @@ def cpu_baseline(args):
                 "sample": f"cpu baseline leg failed: {type(e).__name__}: {e}"}
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without an external launcher: start N FRESH interpreters of this script, one rank per GPU, with
+    the env:// rendezvous the reference's ddp_train.py reads (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT,
+    ddp_train.py:64-81), wait for all of them, relay rank 0's single JSON line, and fail if any rank fails.  This process
+    has not touched the GPU (no HIP call before this point) and never execs: the ranks are ordinary child processes."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                LOCAL_WORLD_SIZE=str(args.gpus))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between the ranks on this host driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    pending = set(range(args.gpus))
+    while pending and failed is None:
+        for r in list(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0 and failed is None:
+                    failed = (r, rc)
+        if pending and failed is None:
+            time.sleep(0.05)          # (rank 0's stdout carries one short line at its very end: the pipe cannot fill up meanwhile)
+    if failed is not None:                  # one rank died: the others would wait in the rendezvous / a collective for ever
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print(f"[bench] rank {failed[0]} exited with code {failed[1]}", file=sys.stderr, flush=True)
+        sys.exit(failed[1] if 0 < failed[1] < 256 else 1)
+    out = procs[0].stdout.read().decode()
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    if not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        sys.exit(1)
+    print(lines[-1], flush=True)
+
+
+def dry_launch(args):
+    """Launcher rehearsal (tests/test_ddp_cpu.py): everything bench.py does around the model -- rendezvous, barrier, one
+    all-reduce (max over ranks of a per-rank time), rank 0's one JSON line -- and nothing else."""
+    from medical_image_classification_amd.ddp_train import setup_distributed
+    distributed, rank, world, local_rank = setup_distributed(None)
+    if args.gpus > 1 and (not distributed or world != args.gpus):
+        raise RuntimeError(f"--gpus {args.gpus}: WORLD_SIZE is {world}")
+    on_gpu = distributed and dist.get_backend() == "nccl"
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=f"cuda:{local_rank}" if on_gpu else "cpu")
+    if distributed:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry-launch", "value": t.item(), "unit": "ranks", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "backend": dist.get_backend() if distributed else None}), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(args)), flush=True)
+        return
+    if args.gpus > 1 and "RANK" not in os.environ:          # before the first torch.cuda.* call of this process
+        self_launch(args)
+        return
+    if args.dry_launch:
+        dry_launch(args)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,10 +245,9 @@ def main():
     os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
-    if world != args.gpus:
-        if args.gpus > 1:
-            raise RuntimeError(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                               f"(WORLD_SIZE is {world})")
+    if world != args.gpus and args.gpus > 1:
+        raise RuntimeError(f"--gpus {args.gpus}: launched with WORLD_SIZE {world} (torch.distributed.run --nproc-per-node must "
+                           f"equal --gpus; without a launcher bench.py starts its own ranks)")
     from medical_image_classification_amd import selective_scan_interface as ssi
     from medical_image_classification_amd.ddp_train import setup_distributed, wrap_ddp
     from medical_image_classification_amd.train import build_model, make_adam, synthetic_batch, train_step

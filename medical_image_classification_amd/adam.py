@@ -65,7 +65,23 @@ class MsAdam(torch.optim.Adam):
         self._ms_tables[gi] = [key, launches, ts.pop()]
         return launches, self._ms_tables[gi][2]
 
+    def load_state_dict(self, state_dict):
+        """torch's `Optimizer.load_state_dict` leaves `state['step']` where the checkpoint was mapped (`map_location=device` puts every
+        counter on the GPU for non-fused groups); the one-launch path keeps the counters on the host, so they are brought back here --
+        otherwise every step after a resume would silently run torch's foreach implementation with ~2 host syncs per parameter."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            s = st.get("step")
+            if torch.is_tensor(s) and s.device.type != "cpu":
+                st["step"] = s.detach().to("cpu", torch.float32)
+        self._ms_tables.clear()
+
     def step(self, closure=None):
+        # the closure first, as torch.optim.Adam.step does: it may (re)create the gradient tensors the lists below refer to
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         # first pass: the tensor lists of every group (creates missing state, as torch's step does) and whether the one-launch path
         # serves all of them; if not, torch's own implementation runs the whole step
         work = []
@@ -82,12 +98,9 @@ class MsAdam(torch.optim.Adam):
                     ok = False
                 if not ok:
                     self._ms_tables.clear()              # torch's step advances the counters: the cached count would go stale
-                    return super().step(closure)
+                    super().step(None)                   # (the closure has already been evaluated)
+                    return loss
                 work.append((gi, group, params, grads, launches, t, steps))
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
         with torch.no_grad():
             for gi, group, params, grads, launches, t, steps in work:
                 torch._foreach_add_(steps, 1)            # host scalars (one C++ loop); every parameter keeps its own, as torch.optim.Adam does

@@ -101,7 +101,7 @@ class _LayerNormTaps(torch.autograd.Function):
 
 def layernorm_taps_ok(x, norm):
     return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
-            and x.shape[3] % 4 == 0 and 4 * x.shape[3] <= 1024 and x.data_ptr() % 16 == 0 and type(norm) is torch.nn.LayerNorm
+            and x.shape[3] % 4 == 0 and 4 * x.shape[3] <= 2048 and x.data_ptr() % 16 == 0 and type(norm) is torch.nn.LayerNorm
             and norm.elementwise_affine and norm.bias is not None and tuple(norm.normalized_shape) == (4 * x.shape[3],))
 
 

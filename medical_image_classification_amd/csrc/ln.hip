@@ -10,7 +10,7 @@
 
 namespace ms {
 
-constexpr int kLnMaxVPT = 16;          // D <= 1024
+constexpr int kLnMaxVPT = 32;          // D <= 2048
 
 __device__ __forceinline__ float ln_wave_sum(float v) {
 #pragma unroll
@@ -345,7 +345,7 @@ ln_bwd_sub_kernel(const float *__restrict__ x, int64_t xps, const float *__restr
 #define MS_LN_DISPATCH(VPTVAR, CALL)                                                                            \
     if (VPTVAR <= 1) { CALL(1); } else if (VPTVAR <= 2) { CALL(2); } else if (VPTVAR <= 3) { CALL(3); }           \
     else if (VPTVAR <= 4) { CALL(4); } else if (VPTVAR <= 6) { CALL(6); } else if (VPTVAR <= 8) { CALL(8); }      \
-    else if (VPTVAR <= 12) { CALL(12); } else { CALL(16); }
+    else if (VPTVAR <= 12) { CALL(12); } else if (VPTVAR <= 16) { CALL(16); } else if (VPTVAR <= 24) { CALL(24); } else { CALL(32); }
 
 int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float *beta, float eps, void *out,
                     int out_bf16, int64_t npix, int D, hipStream_t s) {
@@ -357,7 +357,7 @@ int ln_fwd_dispatch(const float *x, int64_t xps, const float *gamma, const float
         const dim3 g((unsigned)((npix + per - 1) / per));                                                                       \
         if (out_bf16) hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (unsigned short *)out, D, npix, LnTaps{0, 0, 0}); \
         else hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, beta, eps, (float *)out, D, npix, LnTaps{0, 0, 0}); } while (0)
-        MS_LN_SUB_DISPATCH(D, MS_S)
+        MS_LN_SUB_DISPATCH_WIDE(D, MS_S)
 #undef MS_S
         return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
     }
@@ -389,7 +389,7 @@ int ln_bwd_dispatch(const float *x, int64_t xps, const float *gamma, float eps, 
         const dim3 g((unsigned)(nb < cap2 ? nb : cap2));                                                                        \
         if (dout_bf16) hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, unsigned short>), g, dim3(256), 0, s, x, xps, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix, LnTaps{0, 0, 0}); \
         else hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, float>), g, dim3(256), 0, s, x, xps, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix, LnTaps{0, 0, 0}); } while (0)
-        MS_LN_SUB_DISPATCH(D, MS_S)
+        MS_LN_SUB_DISPATCH_WIDE(D, MS_S)
 #undef MS_S
         return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
     }
@@ -430,7 +430,7 @@ int ln_taps_fwd_dispatch(const float *x, const float *gamma, const float *beta, 
         const dim3 g((unsigned)((npix + per - 1) / per));                                                                       \
         if (out_bf16) hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, unsigned short, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, beta, eps, (unsigned short *)out, D, npix, tp); \
         else hipLaunchKernelGGL((ln_fwd_sub_kernel<L, V, P, float, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, beta, eps, (float *)out, D, npix, tp); } while (0)
-    MS_LN_SUB_DISPATCH(D, MS_S)
+    MS_LN_SUB_DISPATCH_WIDE(D, MS_S)
 #undef MS_S
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
@@ -450,7 +450,7 @@ int ln_taps_bwd_dispatch(const float *x, const float *gamma, float eps, const vo
         const dim3 g((unsigned)(nb < cap2 ? nb : cap2));                                                                        \
         if (dout_bf16) hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, unsigned short, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, eps, (const unsigned short *)dout, dx, dgamma, dbeta, D, npix, tp); \
         else hipLaunchKernelGGL((ln_bwd_sub_kernel<L, V, P, float, true>), g, dim3(256), 0, s, x, (int64_t)D, gamma, eps, (const float *)dout, dx, dgamma, dbeta, D, npix, tp); } while (0)
-    MS_LN_SUB_DISPATCH(D, MS_S)
+    MS_LN_SUB_DISPATCH_WIDE(D, MS_S)
 #undef MS_S
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }

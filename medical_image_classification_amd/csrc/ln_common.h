@@ -44,6 +44,10 @@ __device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.
     if ((D) <= 64) { CALL(16, 1, 4); } else if ((D) <= 128) { CALL(32, 1, 4); } else if ((D) <= 256) { CALL(64, 1, 4); } \
     else if ((D) <= 512) { CALL(64, 2, 2); } else if ((D) <= 768) { CALL(64, 3, 1); } else { CALL(64, 4, 1); }
 
+// ln.hip only: rows up to 2048 channels (PatchMerging2D's LayerNorm over 4 x 384 / 4 x 512 channels in front of stage 3, MedMamba.py:196-205)
+#define MS_LN_SUB_DISPATCH_WIDE(D, CALL)                                                                   \
+    if ((D) <= 1024) { MS_LN_SUB_DISPATCH(D, CALL) } else if ((D) <= 1536) { CALL(64, 6, 1); } else { CALL(64, 8, 1); }
+
 static inline bool ln_aligned(const void *p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 }  // namespace ms

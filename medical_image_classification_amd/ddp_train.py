@@ -113,6 +113,12 @@ class FlatGradDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         # arm the slice counters for the backward of this forward (training only)
         if torch.is_grad_enabled() and self.module.training:
+            if self._works:
+                # a backward whose slices went out but were never reduced (gradient accumulation without reduce_gradients()):
+                # the in-place collectives may still be writing the flat buffer the next backward packs into
+                raise RuntimeError("FlatGradDataParallel: the previous backward's all-reduces are still outstanding -- call "
+                                   "reduce_gradients() between backward() and the next forward (one all-reduce round per "
+                                   "forward/backward; gradient accumulation over several forwards is not supported)")
             self._left = [hi - lo for lo, hi, _, _ in self.slices]
             self._next = len(self.slices) - 1
             self._works = []
@@ -250,14 +256,17 @@ def main(argv=None):
             running += loss.item()
         if hasattr(ddp_net, "sync_buffers"):
             ddp_net.sync_buffers()              # rank 0's BatchNorm statistics everywhere before they are saved / evaluated
-        # validation on rank 0 only, as the reference does (ddp_train.py:171-187), on a synthetic batch
+        # validation: EVERY rank evaluates the (unsharded) validation set, as in the reference (ddp_train.py:171-181: the val loader
+        # has no DistributedSampler); rank 0 logs and saves on a strict improvement (`>`, ddp_train.py:186).  Synthetic batch, drawn
+        # from one generator seed on all ranks so that they evaluate the same images.
+        net.eval()
+        with torch.no_grad():
+            vgen = torch.Generator(device=device).manual_seed(4321 + epoch)
+            images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, vgen)
+            acc = (net(images).argmax(dim=1) == labels).sum().item() / args.batch_size
         if rank == 0:
-            net.eval()
-            with torch.no_grad():
-                images, labels = synthetic_batch(args.batch_size, args.num_classes, args.res, device, gen)
-                acc = (net(images).argmax(dim=1) == labels).sum().item() / args.batch_size
             print(f"[epoch {epoch + 1}] train_loss: {running / args.steps_per_epoch:.3f}  val_accuracy: {acc:.3f}")
-            if acc >= best_acc:                 # checkpoint on improvement (ddp_train.py:188-194)
+            if acc > best_acc:                  # checkpoint on improvement (ddp_train.py:186-194)
                 best_acc = acc
                 torch.save({"epoch": epoch, "model": net.state_dict(), "optimizer": optimizer.state_dict(),
                             "best_acc": best_acc}, args.save_path)

@@ -240,7 +240,7 @@ def _norm_rows(norm, x, out_bf16=None):
     """`norm(x)` through ms_layernorm_* when `norm` is a plain affine LayerNorm over the last axis of a CUDA tensor
     (out_bf16=None: the ambient autocast dtype, for a LayerNorm that feeds a projection); the module itself otherwise."""
     if BLOCK_FUSED and x.is_cuda and type(norm) is nn.LayerNorm and norm.elementwise_affine and norm.bias is not None \
-            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == x.shape[-1] <= 1024:
+            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == x.shape[-1] <= 2048:
         return layernorm_rows(x, norm.weight, norm.bias, norm.eps, out_bf16)
     return norm(x)
 

@@ -42,6 +42,8 @@ class _Registry:
         self.params = []          # ids, registration order
         self.epoch = 0
         self.table = None         # (key, device tensor holding the descriptors, device block table, n_blocks)
+        self.stream = None        # raw handle of the stream the last whole-model refresh was launched on
+        self.event = None         # recorded behind that launch: a request from ANOTHER stream waits for it (two-stream blocks)
 
 
 _REG = {}
@@ -121,6 +123,11 @@ def _refresh(reg, device, only=None):
     _, tab, bt, n_blocks = table
     with _lib.on_device(device):
         _lib.check(_lib.lib().ms_cast_bf16_multi(tab.data_ptr(), bt.data_ptr(), n_blocks, _lib.current_stream_ptr(device)), "ms_cast_bf16_multi")
+    if only is None:
+        reg.stream = _lib.current_stream_ptr(device).value
+        if reg.event is None:
+            reg.event = torch.cuda.Event()
+        reg.event.record(torch.cuda.current_stream(device))
     for p, sh in todo:
         sh.version, sh.ptr, sh.epoch = p._version, p.data_ptr(), reg.epoch
 
@@ -154,4 +161,8 @@ def bf16(p, conv=False, in_backward=False):
             sh.epoch = reg.epoch - 1               # current for THIS backward, still due for the next forward's refresh
     elif _stale(p, sh, reg.epoch):
         _refresh(reg, p.device)
+    elif reg.event is not None and _lib.current_stream_ptr(p.device).value != reg.stream:
+        # the epoch bookkeeping is host-side: a copy that is "fresh" may have been refreshed by a launch on another stream (the conv
+        # branch's side stream made the step's first request) that this stream's kernels are not ordered behind
+        torch.cuda.current_stream(p.device).wait_event(reg.event)
     return sh.t

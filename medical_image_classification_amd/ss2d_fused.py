@@ -330,7 +330,7 @@ class _SS2DInner(torch.autograd.Function):
     concat)."""
 
     @staticmethod
-    def forward(ctx, xz, conv_w, conv_b, xproj_w, wdt, A_logs, Ds, dt_bias, gamma, beta, eps, N, R, out_bf16, mm_dtype):
+    def forward(ctx, xz, conv_w, conv_b, xproj_w, wdt, A_logs, Ds, dt_bias, gamma, beta, eps, N, R, out_bf16, mm_dtype, want_grad=True):
         _lib.require_cuda(xz, conv_w, xproj_w, wdt, A_logs, Ds, dt_bias, gamma, beta)
         lib = _lib.lib()
         B, H, W, D2 = xz.shape
@@ -365,7 +365,10 @@ class _SS2DInner(torch.autograd.Function):
                 proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())
             # inference (no gradient wanted): the Delta projection is formed inside the scan kernel (MS_SCAN_DT_FUSED) --
             # no dt_proj launch, no delta tensor, no saved states.  Training materialises delta: the backward kernel reads it.
-            fuse_dt = (not any(ctx.needs_input_grad)) and N == 16 and R <= 32 and D % 4 == 0
+            # `want_grad`: under torch.no_grad() `needs_input_grad` still mirrors the parameters' requires_grad, so the wrapper passes
+            # whether a graph is being recorded at all (the validation loop of train.py:82-95 is eval() + no_grad())
+            need_bwd = want_grad and any(ctx.needs_input_grad)
+            fuse_dt = (not need_bwd) and N == 16 and R <= 32 and D % 4 == 0
             act = (not fuse_dt) and _dt_act_ok(R)          # delta' = softplus(delta + bias) formed by the projection kernel
             delta = None if fuse_dt else _dtproj_fwd(proj, wdt, B, L, D, R, C, act_bias=bias if act else None)
             P = MsScanParams()
@@ -380,7 +383,7 @@ class _SS2DInner(torch.autograd.Function):
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")
             # training keeps the MERGED sum of the four direction slabs for the backward (ms_ln_gate_fwd_keep): the LayerNorm
             # backward then reads 4 B instead of 16 B per element and the slabs are released here
-            ysum = torch.empty((B, L, D), device=dev, dtype=torch.float32) if any(ctx.needs_input_grad) else None
+            ysum = torch.empty((B, L, D), device=dev, dtype=torch.float32) if need_bwd else None
             if ysum is None:
                 _lib.check(lib.ms_ln_gate_fwd(y4.data_ptr(), B * L * D, xz.data_ptr() + D * isz, xz_bf16, D2, gamma.data_ptr(),
                                               beta.data_ptr(), float(eps), out.data_ptr(), int(out_bf16), M, D, stream),
@@ -465,7 +468,7 @@ class _SS2DInner(torch.autograd.Function):
                 dcb.data_ptr() if cb is not None else None, B, D, H, W, D2, stream), "ms_dwconv3x3_silu_nhwc_bwd")
         cwd, cbd, wxd, wxs = ctx.dtypes
         return (dxz, dcw.view(cw.shape).to(cwd), (dcb.to(cbd) if cb is not None else None), dwx.view(wxs).to(wxd), dwdt,
-                dA.view(A.shape), dD, dbias, dgamma, dbeta, None, None, None, None, None)
+                dA.view(A.shape), dD, dbias, dgamma, dbeta, None, None, None, None, None, None)
 
 
 def ss2d_inner(xz, mod):
@@ -479,7 +482,7 @@ def ss2d_inner(xz, mod):
     with torch.autocast(device_type="cuda", enabled=False):
         return _SS2DInner.apply(xz, mod.conv2d.weight, mod.conv2d.bias, mod.x_proj_weight, mod.dt_projs_weight, mod.A_logs,
                                 mod.Ds.view(-1), mod.dt_projs_bias.view(-1), mod.out_norm.weight, mod.out_norm.bias,
-                                mod.out_norm.eps, mod.d_state, mod.dt_rank, out_bf16, mm_dtype)
+                                mod.out_norm.eps, mod.d_state, mod.dt_rank, out_bf16, mm_dtype, torch.is_grad_enabled())
 
 
 def _projections(xc, x_proj_weight, dt_projs_weight, d_state, dt_rank):

@@ -98,7 +98,7 @@ def main(argv=None):
             acc = (net(images).argmax(dim=1) == labels).sum().item() / args.batch_size
         print(f"[epoch {epoch + 1}] train_loss: {running_loss / args.steps_per_epoch:.3f}  val_accuracy: {acc:.3f}  "
               f"{args.steps_per_epoch * args.batch_size / dt:.1f} images/s")
-        if acc >= best_acc:
+        if acc > best_acc:                      # strict improvement, as train.py:101
             best_acc = acc
             torch.save(net.state_dict(), args.save_path)
     print("Finished Training")

@@ -50,3 +50,30 @@ def test_single_process_fallback(monkeypatch):
     import torch.nn as nn
     m = nn.Linear(2, 2)
     assert wrap_ddp(m, False, 0) is m
+
+
+def _bench(args, **env):
+    e = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT, **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=300)
+
+
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python bench.py --gpus N` as the driver may start it, with no torch.distributed.run around it: bench.py starts N fresh rank
+    processes with the env:// rendezvous variables of ddp_train.py:64-81 and relays rank 0's ONE JSON line.  --dry-launch = the
+    rendezvous, a barrier, one all-reduce and the JSON line without the model (gloo here; the GPU rehearsal runs the model)."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch"], MEDSCAN_DIST_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                   # stdout carries exactly one line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] == 2.0 and j["backend"] == "gloo" and j["steps"] == 3 and j["warmup"] == 1
+
+
+def test_bench_self_launch_fails_when_a_rank_fails():
+    r = _bench(["--gpus", "2", "--dry-launch"], MEDSCAN_DIST_BACKEND="no_such_backend")
+    assert r.returncode != 0
+    assert not r.stdout.decode().strip()                            # no JSON line from a failed job

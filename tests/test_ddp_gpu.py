@@ -45,3 +45,24 @@ def test_flat_grad_data_parallel_one_rank_matches_plain_training():
             assert float((p - q).abs().max()) <= 5e-3 * max(1e-2, float(p.abs().max())), n
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_self_launch_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it, on the one GPU of this box: bench.py starts two rank processes (both on
+    cuda:0, gloo as the transport -- RCCL refuses two ranks on one device), each runs the real model step under the data-parallel
+    wrapper, rank 0 prints ONE parsable JSON line with n_gpus 2.  What it cannot show is RCCL over xGMI: that is the driver's 8-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEDSCAN_DIST_BACKEND="gloo", PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch-size", "4", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["config"]["parallelism"] == "dp2"
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0 and "cpu_baseline" not in j

@@ -163,7 +163,8 @@ def test_medmamba_t_stage_block_vs_oracle():
     xr = x.clone().requires_grad_(); xd = x.to(dev()).requires_grad_()
     yr = ref(xr); yd = blk(xd)
     yr.backward(g); yd.backward(g.to(dev()))
-    # composite block (BatchNorm with batch statistics + dense 3x3 convs on MIOpen vs CPU): max-norm relative
+    # composite block in fp32 (BatchNorm with batch statistics; an fp32 run keeps the dense 3x3 convs on MIOpen -- the bf16 twin that
+    # runs conv3x3.hip / ms_gemm_bf16 in situ is tests/test_train_parity_gpu.py::test_medmamba_t_stage_block_bf16_vs_oracle): max-norm relative
     assert_close(yd, yr.detach().numpy(), 1e-3, 1e-3 * float(yr.abs().max()), "y")
     assert_close(xd.grad, xr.grad.numpy(), 2e-3, 5e-3 * float(xr.grad.abs().max()), "dx")   # 2 of 301k elements differ by 2.5e-3*max via the BN/MIOpen conv branch
     pr = dict(ref.named_parameters())
@@ -370,7 +371,7 @@ def test_medmamba_b_512_train_step_runs():
     assert not torch.equal(before, net.head.weight.detach())
 
 
-@pytest.mark.parametrize("cfg", [(2, 6, 9, 96), (1, 7, 7, 768), (3, 2, 5, 70), (1, 1, 1, 130), (2, 56, 56, 48)])
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 96), (1, 7, 7, 768), (3, 2, 5, 70), (1, 1, 1, 130), (2, 56, 56, 48), (2, 7, 7, 1536), (1, 3, 5, 2048), (1, 2, 3, 1090)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_layernorm_rows_strided_vs_torch(cfg, bf16):
     """ms_layernorm_fwd/bwd on the right half of a (B,H,W,2D) tensor read in place, against F.layer_norm in float64."""

@@ -391,6 +391,63 @@ def test_ms_adam_matches_torch_adam_and_shares_its_state_dict():
     assert float(oc.state_dict()["state"][0]["step"]) == 1.0
 
 
+def test_ms_adam_step_with_a_closure_matches_torch_adam():
+    """`optimizer.step(closure)`: torch.optim.Adam evaluates the closure FIRST and updates with the gradients it produced; a closure
+    that does zero_grad(set_to_none=True) + backward creates NEW gradient tensors, so an implementation that collected the gradient
+    lists before calling it would update with the previous step's gradients (or, on the very first step, not at all)."""
+    from medical_image_classification_amd.adam import MsAdam
+    torch.manual_seed(11)
+    w0 = torch.randn(300, 17, device=dev()); x = torch.randn(64, 17, device=dev()); y = torch.randn(64, 300, device=dev())
+    pa, pb = nn.Parameter(w0.clone()), nn.Parameter(w0.clone())
+    oa, ob = MsAdam([pa], lr=1e-2), torch.optim.Adam([pb], lr=1e-2, foreach=False, fused=False)
+
+    def closure_for(p, opt, it):
+        def closure():
+            opt.zero_grad(set_to_none=True)
+            loss = ((x * (1.0 + it)) @ p.t() - y).square().mean()
+            loss.backward()
+            return loss
+        return closure
+
+    for it in range(4):
+        la = oa.step(closure_for(pa, oa, it)); lb = ob.step(closure_for(pb, ob, it))
+        assert la is not None and abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=4e-6, atol=2e-7)
+    assert oa._ms_tables, "the one-launch path served the closure steps"
+    assert float(oa.state_dict()["state"][0]["step"]) == 4.0
+
+
+def test_ms_adam_resume_with_device_mapped_checkpoint_stays_on_the_one_launch_path(tmp_path):
+    """ddp_train.py:142-150 (`--resume`): the checkpoint is loaded with `map_location=device`, which puts every `state['step']` on the
+    GPU; MsAdam.load_state_dict brings the counters back to the host so that the step after a resume is still ms_adam_multi (and equals
+    torch's Adam continued from the same state)."""
+    from medical_image_classification_amd.adam import MsAdam
+    torch.manual_seed(12)
+    base = [torch.randn(s, device=dev()) for s in [(33,), (5000,), (16, 3, 3, 3)]]
+    pa = [nn.Parameter(b.clone()) for b in base]; pb = [nn.Parameter(b.clone()) for b in base]
+    oa, ob = MsAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2, foreach=False, fused=False)
+
+    def grads(step):
+        g = torch.Generator(device=dev()).manual_seed(step)
+        for a, b in zip(pa, pb):
+            a.grad = torch.randn(a.shape, device=dev(), generator=g); b.grad = a.grad.clone()
+
+    for s in range(2):
+        grads(s); oa.step(); ob.step()
+    path = tmp_path / "ck.pth"
+    torch.save({"optimizer": oa.state_dict(), "model": [p.detach() for p in pa]}, path)
+    ck = torch.load(path, map_location=dev(), weights_only=True)
+    assert all(st["step"].is_cuda for st in ck["optimizer"]["state"].values())        # the situation the fix is for
+    oa2 = MsAdam(pa, lr=1e-2)
+    oa2.load_state_dict(ck["optimizer"])
+    assert all(st["step"].device.type == "cpu" for st in oa2.state.values())
+    grads(2); oa2.step(); ob.step()
+    assert oa2._ms_tables, "after a resume the update still runs as one ms_adam_multi launch"
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=4e-6, atol=2e-7)
+    assert float(oa2.state_dict()["state"][0]["step"]) == 3.0
+
+
 @pytest.mark.parametrize("cfg", [(2, 3, 224, 224, 96), (3, 3, 32, 20, 48), (1, 4, 8, 8, 64)])
 def test_patch_embedding_as_im2col_gemm(cfg):
     """PatchEmbed2D's 4 x 4 / stride 4 convolution under bf16 autocast = ms_patchify4_bf16 + ms_gemm_bf16_bias_act, its weight / bias
@@ -424,7 +481,7 @@ def test_patch_embedding_as_im2col_gemm(cfg):
         assert not _patch_embed_gemm_ok(pe.proj, x.clone().requires_grad_())
 
 
-@pytest.mark.parametrize("cfg", [(2, 56, 56, 96), (3, 6, 10, 12), (1, 14, 14, 192), (2, 4, 2, 256)])
+@pytest.mark.parametrize("cfg", [(2, 56, 56, 96), (3, 6, 10, 12), (1, 14, 14, 192), (2, 4, 2, 256), (2, 14, 14, 384), (1, 6, 4, 512)])   # last two: 1536 / 2048 channels (T / B stage 3)
 @pytest.mark.parametrize("bf16", [False, True])
 def test_patch_merging_gather_inside_the_layernorm(cfg, bf16):
     """ms_layernorm_taps_fwd/bwd (PatchMerging2D's 2 x 2 tap gather as an addressing mode of its LayerNorm, the scatter of the dx

@@ -1,0 +1,219 @@
+"""The path bench.py times, held to the oracle END TO END: bf16-autocast, training-mode MedMamba at the MedMamba-T widths
+(dims 96/192/384/768, one block per stage) through `train.train_step` + `make_adam` (= MsAdam) for three optimizer steps on the
+GPU, against the same initial weights through `oracle/ss2d_oracle` in fp32 on the CPU with torch.optim.Adam.
+
+In situ this exercises what the unit tests pin piece by piece: `ms_gemm_bf16` (in_proj / x_proj / out_proj / 1x1 conv / patch
+embedding / PatchMerging), `conv3x3.hip` at 48..384 channels, the BatchNorm kernels on bf16, `dtproj` at the real ranks 3/6/12/24,
+`shadow.py`'s bf16 weight copies and their refresh after every optimizer step, `arena.py`'s zero buffers, `ms_adam_multi`.  Steps 2
+and 3 are the point: a stale weight copy or a re-used arena region cannot show in step 1.  Reference loop: train.py:66-80; block:
+MedMamba.py:502-538.
+
+Bounds.  The fp32 build of the same model agrees with the oracle to 1e-3 (second test below), so everything beyond that is what
+bf16 autocast itself costs at this depth and batch size -- and that is MEASURED in the test, not assumed: the YARDSTICK is the CPU
+oracle model under stock `torch.autocast("cpu", bfloat16)` (torch's own bf16 Linear / Conv2d around the fp32 scan, its own Adam)
+started from the same weights.  At batch 2 the yardstick's gradients differ from fp32 by up to 0.23 relative L2 (cosine 0.973) in
+the conv branch of the early stages (batch-statistics BatchNorm over few samples amplifies the bf16 rounding of its input), 0.005
+at stage 3; this package's bf16 path tracks it parameter by parameter (tools/diag_bf16_parity.py prints the table).
+  * loss per step            |rel| <= 2e-2
+  * logits per step          max-norm <= 6e-2 of max|logit|
+  * every parameter gradient, every step: relative L2 error vs fp32 <= 1.5 x the yardstick's for that parameter + 0.02, and in
+    absolute terms (a sanity net under the yardstick bound) cosine >= 0.9, relative L2 <= 0.45; mean cosine over all parameters >= the yardstick's mean - 0.005 and >= 0.97
+  * conv biases that feed a training-mode BatchNorm have a mathematically ZERO gradient (the mean subtraction removes them): the
+    fp32 oracle holds rounding noise there and this package returns exact zeros (the bias is folded into the BatchNorm shift), so
+    they are held to "tiny" (<= 1e-3 of the largest gradient norm) instead of a direction
+  * parameter change after the 3 steps: Adam's first steps move every element by ~lr * sign(g), so an element whose gradient is
+    below the bf16 noise flips its direction: cosine vs the fp32 trajectory >= the yardstick's - 0.1 and >= 0.7 per tensor
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from oracle import ss2d_oracle
+
+pytestmark = pytest.mark.gpu
+
+DIMS, CLASSES, LR = [96, 192, 384, 768], 8, 1e-4          # lr: the reference's own (train.py:62)
+
+
+class _DenseOpAudit(TorchDispatchMode):
+    """Every library convolution / GEMM an aten op would launch (hipBLASLt `Cijk_*`, MIOpen) passes through one of these ops."""
+    WATCH = ("convolution", "convolution_backward", "miopen_convolution", "cudnn_convolution", "_convolution", "mm", "addmm", "bmm",
+             "baddbmm", "linear", "matmul", "_scaled_mm", "miopen_batch_norm", "native_batch_norm", "cudnn_batch_norm",
+             "native_layer_norm", "_native_batch_norm_legit")
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split(".")[0]
+        if name in self.WATCH:
+            self.calls.append((name, [tuple(a.shape) for a in args if isinstance(a, torch.Tensor)]))
+        return func(*args, **(kwargs or {}))
+
+
+def _zero_grad_by_construction(name):
+    """conv biases in front of a training-mode BatchNorm (MedMamba.py:517-523: BN -> conv3x3 -> BN -> ReLU -> conv3x3 -> BN)."""
+    return name.endswith("conv33conv33conv11.1.bias") or name.endswith("conv33conv33conv11.4.bias")
+
+
+def _cos_rel(a, r):
+    a, r = a.double().flatten(), r.double().flatten()
+    return (float(a @ r / (a.norm() * r.norm()).clamp_min(1e-300)), float((a - r).norm() / r.norm().clamp_min(1e-300)))
+
+
+def _run_three_steps(bf16):
+    """(GPU build in bf16 autocast or fp32) vs the fp32 CPU oracle (+ the stock-autocast yardstick when bf16): per-step records."""
+    from medical_image_classification_amd import medmamba as mm
+    from medical_image_classification_amd.adam import MsAdam
+    from medical_image_classification_amd.train import make_adam, train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    kw = dict(depths=[1, 1, 1, 1], dims=DIMS, num_classes=CLASSES, drop_path_rate=0.0)
+    net, ref, yard = mm.VSSM(**kw), mm.VSSM(**kw), mm.VSSM(**kw)
+    ref.load_state_dict(net.state_dict()); yard.load_state_dict(net.state_dict())
+    ss2d_oracle.install(ref); ss2d_oracle.install(yard)
+    init = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(dev).train(); ref.train(); yard.train()
+    x = torch.randn(2, 3, 224, 224); y = torch.tensor([1, 6])
+    xd, yd = x.to(dev), y.to(dev)
+    opt = make_adam(net.parameters(), lr=LR)
+    opt_ref, opt_yard = torch.optim.Adam(ref.parameters(), lr=LR), torch.optim.Adam(yard.parameters(), lr=LR)
+    assert isinstance(opt, MsAdam)
+    lossf = nn.CrossEntropyLoss()
+    logits = {}
+    net.head.register_forward_hook(lambda _m, _i, o: logits.__setitem__("gpu", o.detach().float().cpu()))
+    ref.head.register_forward_hook(lambda _m, _i, o: logits.__setitem__("cpu", o.detach().float()))
+    pr, py = dict(ref.named_parameters()), dict(yard.named_parameters())
+    steps, audit = [], None
+    for step in range(3):
+        if step == 2:
+            audit = _DenseOpAudit()
+            with audit:
+                loss = train_step(net, opt, lossf, xd, yd, torch.bfloat16 if bf16 else None)
+        else:
+            loss = train_step(net, opt, lossf, xd, yd, torch.bfloat16 if bf16 else None)
+        opt_ref.zero_grad(set_to_none=True)
+        loss_ref = lossf(ref(x), y)
+        loss_ref.backward()
+        if bf16:
+            opt_yard.zero_grad(set_to_none=True)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                loss_yard = lossf(yard(x).float(), y)
+            loss_yard.backward()
+        # gradients of this step (train_step zeroes at its START, so they are still there), before the CPU models' updates
+        rec = {"loss": float(loss.detach()), "loss_ref": float(loss_ref.detach()), "logits": logits["gpu"], "logits_ref": logits["cpu"],
+               "gmax": max(float(p.grad.norm()) for p in pr.values()), "grads": {}}
+        for k, p in net.named_parameters():
+            g, r = p.grad.detach().float().cpu(), pr[k].grad
+            rec["grads"][k] = (_cos_rel(g, r), _cos_rel(py[k].grad, r) if bf16 else None, float(g.norm()), float(r.norm()))
+        steps.append(rec)
+        opt_ref.step()
+        if bf16:
+            opt_yard.step()
+    delta = {}
+    for k, p in net.named_parameters():
+        d_r = pr[k].detach() - init[k]
+        delta[k] = (_cos_rel(p.detach().cpu() - init[k], d_r), _cos_rel(py[k].detach() - init[k], d_r) if bf16 else None)
+    return net, ref, steps, delta, audit
+
+
+def test_bf16_autocast_training_steps_match_fp32_cpu_oracle():
+    net, ref, steps, delta, audit = _run_three_steps(bf16=True)
+    for i, rec in enumerate(steps):
+        lg, lr_ = rec["loss"], rec["loss_ref"]
+        assert abs(lg - lr_) <= 2e-2 * abs(lr_), f"step {i}: loss {lg} vs {lr_}"
+        assert float((rec["logits"] - rec["logits_ref"]).abs().max()) <= 6e-2 * float(rec["logits_ref"].abs().max()), f"step {i}: logits"
+        coss, ycoss, worst, ratio = [], [], (1.0, ""), (0.0, "")
+        for k, ((cos, rel), (ycos, yrel), gn, rn) in rec["grads"].items():
+            if _zero_grad_by_construction(k):
+                assert rn <= 1e-3 * rec["gmax"] and gn <= 1e-3 * rec["gmax"], (i, k, gn, rn)
+                continue
+            coss.append(cos); ycoss.append(ycos)
+            worst = min(worst, (cos, k))
+            ratio = max(ratio, (rel / max(yrel, 1e-3), k))
+            assert rel <= 1.5 * yrel + 0.02, f"step {i}: d{k}: rel L2 {rel:.4f} vs stock bf16 autocast {yrel:.4f}"
+            assert cos >= 0.9 and rel <= 0.45, f"step {i}: d{k}: cosine {cos:.5f}, rel L2 {rel:.4f}"
+        print(f"step {i}: loss {lg:.5f} vs {lr_:.5f}; gradient cosine worst {worst[0]:.5f} ({worst[1]}), mean {np.mean(coss):.6f}; "
+              f"(stock autocast: worst {min(ycoss):.5f}, mean {np.mean(ycoss):.6f}); largest rel-L2 ratio to it {ratio[0]:.2f} ({ratio[1]})")
+        assert np.mean(coss) >= np.mean(ycoss) - 0.005 and np.mean(coss) >= 0.97
+    # no library convolution / BatchNorm / LayerNorm, and no library GEMM besides the classifier head (768 -> 8: one addmm forward, two
+    # mm backward): everything else of the (third) step ran on this package's kernels
+    convs = [c for c in audit.calls if "conv" in c[0] or "norm" in c[0]]
+    assert not convs, convs
+    gemms = [c for c in audit.calls if c[0] in ("mm", "addmm", "bmm", "baddbmm", "matmul", "linear", "_scaled_mm")]
+    assert len(gemms) <= 3 and all(any(CLASSES in s for s in shapes) for _, shapes in gemms), gemms
+    # the same batch three times (fp32 CPU losses 2.28 -> 1.09 -> 0.47): the loss must fall visibly on BOTH sides (a forward that
+    # still used the initial weights -- a stale bf16 copy -- would repeat its first loss)
+    ls = [(r["loss"], r["loss_ref"]) for r in steps]
+    assert ls[1][0] < 0.9 * ls[0][0] and ls[2][0] < 0.9 * ls[1][0], ls
+    assert ls[1][1] < 0.9 * ls[0][1] and ls[2][1] < 0.9 * ls[1][1], ls
+    coss = []
+    for k, ((cos, rel), (ycos, yrel)) in delta.items():
+        if _zero_grad_by_construction(k):
+            continue
+        coss.append(cos)
+        assert cos >= ycos - 0.1 and cos >= 0.7, f"parameter change of {k}: cosine {cos:.4f} (stock autocast {ycos:.4f})"
+    print(f"parameter change over 3 steps: cosine worst {min(coss):.4f}, mean {np.mean(coss):.5f}")
+    assert np.mean(coss) >= 0.9
+    br = dict(ref.named_buffers())          # BatchNorm buffers followed the same batches
+    for k, b in net.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert float((b.cpu() - br[k]).abs().max()) <= 3e-2 * max(1e-2, float(br[k].abs().max())), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(b) == 3
+
+
+def test_fp32_training_steps_match_fp32_cpu_oracle():
+    """The same three steps with fp32 dense ops (the reference's own precision, train.py:57-77): arena, MsAdam, every kernel of the
+    fp32 build against the oracle at the tolerances of the operator tests -- loss 1e-4, gradients 5e-3 relative L2 (cosine
+    0.99999), parameter change after three Adam steps cosine 0.995 (elements with |g| below fp32 noise flip their sign)."""
+    net, ref, steps, delta, audit = _run_three_steps(bf16=False)
+    for i, rec in enumerate(steps):
+        assert abs(rec["loss"] - rec["loss_ref"]) <= 1e-4 * abs(rec["loss_ref"]), (i, rec["loss"], rec["loss_ref"])
+        assert float((rec["logits"] - rec["logits_ref"]).abs().max()) <= 1e-3 * float(rec["logits_ref"].abs().max())
+        worst = (1.0, 0.0, "")
+        for k, ((cos, rel), _y, gn, rn) in rec["grads"].items():
+            if _zero_grad_by_construction(k):
+                assert rn <= 1e-3 * rec["gmax"] and gn <= 1e-3 * rec["gmax"], (i, k, gn, rn)
+                continue
+            worst = min(worst, (cos, rel, k))
+            assert cos >= 0.99999 - 1e-5 * i * 10 and rel <= 5e-3 * (1 + 2 * i), f"step {i}: d{k}: cosine {cos:.7f}, rel L2 {rel:.5f}"
+        print(f"fp32 step {i}: loss {rec['loss']:.6f} vs {rec['loss_ref']:.6f}; worst gradient cosine {worst[0]:.7f} rel {worst[1]:.5f} ({worst[2]})")
+    for k, ((cos, rel), _y) in delta.items():
+        if not _zero_grad_by_construction(k):
+            assert cos >= 0.995, f"parameter change of {k}: cosine {cos:.5f}"
+
+
+def test_medmamba_t_stage_block_bf16_vs_oracle():
+    """bf16 twin of test_modules_gpu.py::test_medmamba_t_stage_block_vs_oracle: one MedMamba-T stage-1 block (hidden 192 -> SS2D
+    d_model 96, D 192, 28x28) in training mode under bf16 autocast -- ms_gemm_bf16, conv3x3.hip, BatchNorm on bf16 in situ --
+    against the fp32 CPU restatement: output, input gradient, every parameter gradient (cosine / relative L2 as above)."""
+    from medical_image_classification_amd import medmamba as mm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    blk = mm.SS_Conv_SSM(hidden_dim=192, drop_path=0.0)
+    ref = mm.SS_Conv_SSM(hidden_dim=192, drop_path=0.0)
+    ref.load_state_dict(blk.state_dict())
+    ss2d_oracle.install(ref)
+    blk.to(dev).train(); ref.train()
+    x = torch.randn(2, 28, 28, 192); g = torch.randn(2, 28, 28, 192)
+    xr = x.clone().requires_grad_(); xd = x.to(dev).requires_grad_()
+    yr = ref(xr)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yd = blk(xd)
+    yr.backward(g); yd.float().backward(g.to(dev))
+    assert float((yd.detach().float().cpu() - yr.detach()).abs().max()) <= 3e-2 * float(yr.abs().max())
+    dg, dr = xd.grad.cpu().double().flatten(), xr.grad.double().flatten()
+    assert float(dg @ dr / (dg.norm() * dr.norm())) >= 0.999 and float((dg - dr).norm() / dr.norm()) <= 3e-2
+    pr = dict(ref.named_parameters())
+    gmax = max(float(p.grad.norm()) for p in pr.values())
+    for k, p in blk.named_parameters():
+        a, r = p.grad.detach().float().cpu().double().flatten(), pr[k].grad.double().flatten()
+        if _zero_grad_by_construction(k):
+            assert float(a.norm()) <= 1e-3 * gmax and float(r.norm()) <= 1e-3 * gmax, k
+            continue
+        cos = float(a @ r / (a.norm() * r.norm()))
+        assert cos >= 0.995 and float((a - r).norm() / r.norm()) <= 0.1, (k, cos)
