@@ -22,6 +22,7 @@
 // v2f through v_pk_* in both sweeps, the per-position scalars staged as pairs, and the channel sums as a register reduce-scatter
 // (banked DPP adds, scan_common.h chan_scatter8) instead of the LDS transpose -- MS_BWD_PK / MS_BWD_DPP below, DESIGN.md 3.3.
 // The SSD blocks' backward over all four direction slices in one launch is its own kernel: scan_bwd_ssd.hip.
+#include <cstdlib>
 #include "scan_common.h"
 
 namespace ms {
@@ -230,27 +231,41 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             const int n = sg * NPL + i;
             h[i] = (ch > 0 && n < N) ? rx[i] : 0.0f;
         }
+#ifndef MS_ABL_NOBAR
         __syncthreads();                                   // the B/C tiles are staged by all waves of the workgroup
+#endif
         if (ch > 0) fetch(ch - 1);                         // lands while this chunk is computed
 
+#ifdef MS_ABL_NOSWEEP
+        if constexpr (false) {
+#else
         if constexpr (kPk) {
+#endif
             // ================= packed sweeps (same algebra as below, two states per instruction) =================
             const v2f A2p = {A2[0], A2[1]}, Anp = {An[0], An[1]};
             v2f hp = {h[0], h[1]}, dhp = {dhc[0], dhc[1]}, dAp = {dAacc[0], dAacc[1]};
             v2f ap[kCL], ckp[NB];
             const float *sBl = sB + sg * NPL, *sCl = sC + sg * NPL;          // this lane's state pair inside a position row
+            // 4-position batches past the end of the sequence are skipped whole (wave-uniform branch): their elements are the scan
+            // identity (delta' = 0: a = 1, b = 0; dout = 0), so h, dh and every sum pass through them unchanged -- bit-identical, and
+            // L = 49 / 196 (MedMamba-T stages 3 / 2) no longer pay for 15 / 28 padded positions of their last chunk
 #pragma unroll
-            for (int l = 0; l < kCL; ++l) {
-                if ((l & 3) == 0) ckp[l >> 2] = hp;
-                const v2f p1 = sP1[l * kPitch + c], p2 = sP2[l * kPitch + c];      // {delta', u}, {dout, delta' u}
-                const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPk);
-                if constexpr (SA) { const float a = exp2_fast(p1.x * A2[0]); ap[l] = (v2f){a, a}; }      // one decay per channel
-                else ap[l] = exp2_pk((v2f){p1.x, p1.x} * A2p);
-                hp = pk_fma(ap[l], hp, (v2f){p2.y, p2.y} * Bp);
+            for (int kb = 0; kb < NB; ++kb) {
+                if (kb * 4 >= len) continue;
+#pragma unroll
+                for (int l = kb * 4; l < kb * 4 + 4; ++l) {
+                    if ((l & 3) == 0) ckp[l >> 2] = hp;
+                    const v2f p1 = sP1[l * kPitch + c], p2 = sP2[l * kPitch + c];      // {delta', u}, {dout, delta' u}
+                    const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPk);
+                    if constexpr (SA) { const float a = exp2_fast(p1.x * A2[0]); ap[l] = (v2f){a, a}; }      // one decay per channel
+                    else ap[l] = exp2_pk((v2f){p1.x, p1.x} * A2p);
+                    hp = pk_fma(ap[l], hp, (v2f){p2.y, p2.y} * Bp);
+                }
             }
 #pragma unroll
             for (int kb = NB - 1; kb >= 0; --kb) {
                 const int lb = kb * 4;
+                if (lb >= len) continue;
                 v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -280,18 +295,31 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
                     duv[j] = fmaf(s1, p1[j].x, Dv * p2[j].x);
                     ddv[j] = fmaf(s1, p1[j].y, s2);
                 }
+#ifdef MS_ABL_NOSTATE
+                const float du_t = (duv[0] + duv[1]) + (duv[2] + duv[3]), dd_t = (ddv[0] + ddv[1]) + (ddv[2] + ddv[3]);
+#else
                 const float du_t = sum_groups_scatter4<CW>(duv, lane);
                 const float dd_t = sum_groups_scatter4<CW>(ddv, lane);
+#endif
                 if (is_group_owner<CW>(lane)) {
                     const int lo = lb + group_slot<CW>(lane);
                     su[lo * kPitch + c] = du_t;
                     sg_[lo * kPitch + c] = dd_t;
                 }
+#ifdef MS_ABL_NOCHAN
+                sdB[t_dpp + lb] = ((vB8[0] + vB8[1]) + (vB8[2] + vB8[3])) + ((vB8[4] + vB8[5]) + (vB8[6] + vB8[7]));
+                sdC[t_dpp + lb] = ((vC8[0] + vC8[1]) + (vC8[2] + vC8[3])) + ((vC8[4] + vC8[5]) + (vC8[6] + vC8[7]));
+#else
                 sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
                 sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
+#endif
             }
             dhc[0] = dhp.x; dhc[1] = dhp.y; dAacc[0] = dAp.x; dAacc[1] = dAp.y;
+#ifdef MS_ABL_NOSWEEP
+        } else if constexpr (!kPk) {
+#else
         } else {
+#endif
         // ---- forward sweep: the decay a of EVERY position stays in registers (each exp2 is evaluated once per
         //      backward), h only at the start of every 4-position batch ------------------------------------
         constexpr int NA = SA ? 1 : NPL;                       // decays stored per position
@@ -419,6 +447,7 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             pm.tab = spos[ch & 1]; pm.tab_base = l0;
             if (BCM) { pmb.tab = sposb_[wv][ch & 1]; pmb.tab_base = l0; } else pmb = pm;
         }
+#ifndef MS_ABL_NOSTORE
         if (p.delta_softplus & MS_SCAN_ACCUMULATE) {
             tile.template store<true>(su, dub, du_sd, du_sl, l0, pm, nvalid, len);
             tile.template store_ddelta<true>(sg_, sdl, sp_mask, ddb, dd_sd, dd_sl, l0, pm, nvalid, len, dbk);
@@ -426,13 +455,20 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
             tile.store(su, dub, du_sd, du_sl, l0, pm, nvalid, len);
             tile.store_ddelta(sg_, sdl, sp_mask, ddb, dd_sd, dd_sl, l0, pm, nvalid, len, dbk);
         }
+#endif
         // flush the chunk's dB / dC tile (full rows -> 128-byte atomic segments in both row layouts)
         // combine the dB / dC tiles of the workgroup's waves (same batch and group, adjacent channel blocks) and add the
         // sums to global memory: kWPB x fewer atomics than one flush per wave.  One barrier: the tiles are double-buffered
         // by chunk parity, so the next chunk's sweeps write the other buffer while slower waves still read this one, and
         // this buffer is written again only after everyone has passed the NEXT chunk's barrier, i.e. finished this combine.
+#ifndef MS_ABL_NOBAR
         __syncthreads();
+#endif
+#ifdef MS_ABL_NOFLUSH
+        if constexpr (false) {
+#else
         if constexpr (MODE == kModeSS2D && NP == 16 && kWPB == 4 && kCL == 32) {
+#endif
             // thread -> (tensor, state) = tid % 32 fixed, positions tid / 32 + 8 i: a wave's atomics cover two whole projection-row
             // segments [dB(16) | dC(16)] (a version with four consecutive states per thread quadrupled the L2 atomic transactions:
             // 7.3 vs 5.3 ms per step); everything that does not depend on i is hoisted, LDS reads at immediate offsets
@@ -454,7 +490,11 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 #endif
                 }
             }
+#ifdef MS_ABL_NOFLUSH
+        } else if constexpr (false) {
+#else
         } else {
+#endif
             constexpr int NT = 64 * kWPB, TOT = 2 * NP * kCL;
             for (int idx = threadIdx.x; idx < TOT; idx += NT) {
                 const int isC = idx / (NP * kCL), rem = idx % (NP * kCL);
@@ -518,6 +558,8 @@ scan_bwd_kernel(const MsScanBwdParams q, const int n_chunks, const int ncb) {
 int validate_scan(const MsScanParams &p);
 int scan_positions(const MsScanParams &p);
 int ssd_bwd_all_launch(const MsScanBwdParams &q, int n_chunks, hipStream_t stream);
+bool ss2d_bwd_fast_ok(const MsScanBwdParams &q);
+int ss2d_bwd_launch(const MsScanBwdParams &q, int n_chunks, hipStream_t stream);
 int pick_npl(int dstate, int sg);
 bool use_cw8(const MsScanParams &p, bool backward);
 int pick_mode(bool l_contig, bool d_contig, bool small, int map_h);
@@ -581,6 +623,9 @@ int scan_bwd_dispatch(const MsScanBwdParams &q, hipStream_t stream) {
             return MS_ERR_STRIDE;
         return ssd_bwd_all_launch(q, n_chunks, stream);
     }
+    // SS2D training shapes: the software-pipelined fast path (scan_ss2d_bwd.hip); MEDSCAN_BWD_FAST=0 keeps the general kernel (A/B runs)
+    static const bool fast_on = [] { const char *e = getenv("MEDSCAN_BWD_FAST"); return !(e && e[0] == '0'); }();
+    if (fast_on && ss2d_bwd_fast_ok(q)) return ss2d_bwd_launch(q, n_chunks, stream);
     if (use_cw8(p, true)) {
         switch (pick_npl(p.dstate, 8)) {
             case 1: return launch_bwd<1, 8>(q, n_chunks, stream);

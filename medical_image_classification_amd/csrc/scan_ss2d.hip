@@ -123,9 +123,10 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
         }
     }
 
-    const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0w;
-    const float *db = DTF ? nullptr : p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0w;
-    float *ob = p.out + b * p.out_batch_stride + g * p.out_group_stride + c0w;
+    const int c0s = nvalid > 0 ? c0w : 0;                       // a wave past the last channel block loads the group's first channels (in bounds) and stores nothing
+    const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0s;
+    const float *db = DTF ? nullptr : p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0s;
+    float *ob = p.out + b * p.out_batch_stride + g * p.out_group_stride + c0s;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
     const float *Tb = DTF ? p.dt_x + b * p.B_batch_stride + g * p.B_group_stride : nullptr;   // dts: the B rows' strides
@@ -232,6 +233,7 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
 #endif
 #pragma unroll MS_FWD_UNROLL
         for (int lb = 0; lb < kCL; lb += 4) {
+            if (lb >= len) continue;            // batches past the end of the sequence hold the scan identity: skipped whole (wave-uniform)
             float y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
