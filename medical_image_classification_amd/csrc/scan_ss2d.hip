@@ -12,6 +12,7 @@
 // group sg, channel c); workgroup = the waves that share a 128-byte line (32 channels).
 // Everything else (reference (B,D,L) layout, other d_state, scalar-decay SSD forms, unaligned tensors) runs on the
 // general kernels of scan_fwd.hip / scan_bwd.hip.
+#include <type_traits>
 #include "scan_common.h"
 
 namespace ms {
@@ -231,9 +232,13 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
 #ifndef MS_FWD_UNROLL
 #define MS_FWD_UNROLL 8
 #endif
+        // PARTIAL (the sequence's last chunk when L % 32 != 0): 4-position batches past the end hold the scan identity (delta' = 0:
+        // a = 1, b = 0) and are skipped whole -- bit-identical, and L = 49 / 196 (MedMamba-T stages 3 / 2) do not pay for 15 / 28
+        // padded positions.  Full chunks keep the unpredicated loop (one basic block: a guard per batch ends the scheduling region).
+        auto sweep = [&](auto partial) {
 #pragma unroll MS_FWD_UNROLL
         for (int lb = 0; lb < kCL; lb += 4) {
-            if (lb >= len) continue;            // batches past the end of the sequence hold the scan identity: skipped whole (wave-uniform)
+            if (decltype(partial)::value && lb >= len) continue;
             float y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -252,6 +257,8 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
             const float yt = sum_groups_scatter4<CW>(y, lane);
             if (is_group_owner<CW>(lane)) so[(lb + group_slot<CW>(lane)) * CW + c] = yt;
         }
+        };
+        if (len == kCL) sweep(std::false_type()); else sweep(std::true_type());
         if (p.x != nullptr && active) {
 #pragma unroll
             for (int i = 0; i < NPL; ++i)

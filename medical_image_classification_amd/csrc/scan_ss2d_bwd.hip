@@ -14,7 +14,12 @@
 // Specialisation: SS2D addressing (channel-last activations indexed by pixel, projection rows [dts | B | C] contiguous along the
 // state axis), d_state == 16, dense real A, 8-channel waves x 2 states per lane, no MS_SCAN_ACCUMULATE / BC_MAP / LATTICE.
 // Everything else stays on scan_bwd.hip.
+#include <type_traits>
 #include "scan_common.h"
+
+#ifndef MS_BWD_FASTBLOCK
+#define MS_BWD_FASTBLOCK 0      // 1: the steady-state chunk as ONE unpredicated basic block (measured: see DESIGN.md 3.3)
+#endif
 
 namespace ms {
 namespace {
@@ -144,25 +149,28 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
     float4 sig_prev = make_float4(1.f, 1.f, 1.f, 1.f);
     int len_prev = 0;
 
-    // the work of the PREVIOUS chunk (parity pp, positions tabp) that rides inside the sweeps of the current one
-    auto store_du = [&](int pp) {
+    // the work of the PREVIOUS chunk (parity pp, positions tabp) that rides inside the sweeps of the current one.  GUARD = false: the
+    // previous chunk was full and all 8 channels of the wave exist -- no per-lane predicate, so the slices do not split the sweeps'
+    // basic block (a scheduling region ends at every exec-mask change: the sweeps of the steady state are ONE region)
+    auto store_du = [&](int pp, auto guard) {
         const float4 v = ld4b(sOut_[pp][wv][0] + pl * CW + q4);
-        if (pl < len_prev && quad_ok) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
+        if (!decltype(guard)::value || (pl < len_prev && quad_ok)) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
     };
-    auto store_dd = [&](int pp) {
+    auto store_dd = [&](int pp, auto guard) {
         float4 v = ld4b(sOut_[pp][wv][1] + pl * CW + q4);
         v.x *= sig_prev.x; v.y *= sig_prev.y; v.z *= sig_prev.z; v.w *= sig_prev.w;       // d delta = d delta' * softplus'
-        if (pl < len_prev && quad_ok) {
+        if (!decltype(guard)::value || (pl < len_prev && quad_ok)) {
             st4b(atb(ddb, __mul24(pos_prev, dd_sl) + q4), v);
             dbk[0] += v.x; dbk[1] += v.y; dbk[2] += v.z; dbk[3] += v.w;
         }
     };
-    auto flush_piece = [&](int pp, const int *tabp, int i) {
+    auto flush_piece = [&](int pp, const int *tabp, int i, auto guard) {
         const float *src = sdBC_[pp][0] + fsrc + 8 * i;
         const float v = (src[0] + src[kWSb]) + (src[2 * kWSb] + src[3 * kWSb]);
         const int l = flb0 + 8 * i;
-        if (l < len_prev) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
+        if (!decltype(guard)::value || l < len_prev) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
     };
+    using Guarded = std::integral_constant<bool, true>;
 
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
         const int par = ch & 1, len = min(kCL, L - ch * kCL);
@@ -208,11 +216,18 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         const int *tabp = stab[(ch + 1) & 3];
 
         // ---------------- packed sweeps (same algebra as scan_bwd.hip) ----------------
+        // FAST (the steady state: this chunk and the previous one full, all 8 channels present): no predicate anywhere -- one
+        // basic block.  Otherwise 4-position batches past the end of the sequence are skipped whole (they hold the scan identity:
+        // delta' = 0 -> a = 1, b = 0, dout = 0, so h, dh and every sum pass through them unchanged: bit-identical) and the previous
+        // chunk's slices are predicated.
+        auto sweeps = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        using G = std::integral_constant<bool, !FAST>;
         v2f ap[kCL], ckp[NB];
         const float *sBl = sB + sg * 2, *sCl = sC + sg * 2;          // this lane's state pair inside a position row
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
-            if (kb * 4 < len) {
+            if (FAST || kb * 4 < len) {
 #pragma unroll
                 for (int l = kb * 4; l < kb * 4 + 4; ++l) {
                     if ((l & 3) == 0) ckp[l >> 2] = hp;
@@ -222,17 +237,17 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                     hp = pk_fma(ap[l], hp, (v2f){p2.y, p2.y} * Bp);
                 }
             }
-            if (have_prev) {                                       // wave-uniform
-                if (kb == 1) store_du(pp);
-                if (kb == 3) store_dd(pp);
-                if (kb == 5) flush_piece(pp, tabp, 0);
-                if (kb == 7) flush_piece(pp, tabp, 1);
+            if (FAST || have_prev) {                               // wave-uniform
+                if (kb == 1) store_du(pp, G());
+                if (kb == 3) store_dd(pp, G());
+                if (kb == 5) flush_piece(pp, tabp, 0, G());
+                if (kb == 7) flush_piece(pp, tabp, 1, G());
             }
         }
 #pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            if (lb < len) {
+            if (FAST || lb < len) {
                 v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -272,20 +287,23 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                 sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
                 sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
             }
-            if (have_prev) {
-                if (kb == 5) flush_piece(pp, tabp, 2);
-                if (kb == 2) flush_piece(pp, tabp, 3);
+            if (FAST || have_prev) {
+                if (kb == 5) flush_piece(pp, tabp, 2, G());
+                if (kb == 2) flush_piece(pp, tabp, 3, G());
             }
         }
+        };
+        if (MS_BWD_FASTBLOCK && have_prev && len == kCL && len_prev == kCL && nvalid == CW) sweeps(std::integral_constant<bool, true>());
+        else sweeps(std::integral_constant<bool, false>());
         sig_prev = sig_cur; pos_prev = pos_cur; len_prev = len;
     }
     // epilogue: chunk 0's stores and flush
     __syncthreads();
     {
         const int *tabp = stab[0];
-        store_du(0); store_dd(0);
+        store_du(0, Guarded()); store_dd(0, Guarded());
 #pragma unroll
-        for (int i = 0; i < 4; ++i) flush_piece(0, tabp, i);
+        for (int i = 0; i < 4; ++i) flush_piece(0, tabp, i, Guarded());
     }
 
     if (active) {
