@@ -14,11 +14,11 @@
 // Specialisation: SS2D addressing (channel-last activations indexed by pixel, projection rows [dts | B | C] contiguous along the
 // state axis), d_state == 16, dense real A, 8-channel waves x 2 states per lane, no MS_SCAN_ACCUMULATE / BC_MAP / LATTICE.
 // Everything else stays on scan_bwd.hip.
-#include <type_traits>
+#include <cstdlib>
 #include "scan_common.h"
 
-#ifndef MS_BWD_FASTBLOCK
-#define MS_BWD_FASTBLOCK 0      // 1: the steady-state chunk as ONE unpredicated basic block (measured: see DESIGN.md 3.3)
+#ifndef MS_BWD_W3_DEFAULT
+#define MS_BWD_W3_DEFAULT false
 #endif
 
 namespace ms {
@@ -41,16 +41,21 @@ __device__ __forceinline__ float *atb(float *base, int off) {
 }
 
 // PRE: delta already holds delta' = softplus(raw + bias) (MS_SCAN_DELTA_ACTIVATED, the training path)
-template <bool PRE>
-__global__ void __launch_bounds__(kNTb) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// W3: the THREE-waves-per-SIMD build (168 VGPRs, 53.8 KB of LDS per workgroup -> three workgroups per CU): the decays of a chunk are
+//     not kept in registers (64 VGPRs) but evaluated again by the reverse sweep (+64 v_exp, +32 v_pk_mul per chunk, ~9 % more issue
+//     slots), the out tiles and the dB / dC tiles are single-buffered -- every slice of the previous chunk rides in the FORWARD sweep
+//     (which writes neither) and a second barrier separates it from the reverse sweep.  What it buys: a third wave per SIMD to cover
+//     the LDS / exp / DPP latencies, and MedMamba-T's stage 0 (768 workgroups) resident in ONE round instead of 1.5.
+template <bool PRE, bool W3>
+__global__ void __launch_bounds__(kNTb) __attribute__((amdgpu_waves_per_eu(W3 ? 3 : 2, W3 ? 3 : 2)))
 ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
-    constexpr int CW = kCWb, NB = kNBb;
+    constexpr int CW = kCWb, NB = kNBb, NPAR = W3 ? 1 : 2;
     const MsScanParams &p = q.f;
     __shared__ __attribute__((aligned(16))) float sBC[2][2][kCL * kRPb];           // [chunk parity][B | C][position][state]
     __shared__ __attribute__((aligned(16))) v2f sP1_[kNWb][kCL * CW];              // {delta', u}
     __shared__ __attribute__((aligned(16))) v2f sP2_[kNWb][kCL * CW];              // {dout, delta' * u}
-    __shared__ __attribute__((aligned(16))) float sOut_[2][kNWb][2][kCL * CW];     // [parity][wave][du | ddelta'][position][channel]
-    __shared__ float sdBC_[2][kNWb][kWSb];                                          // [parity][wave] dB | dC of the wave's channels
+    __shared__ __attribute__((aligned(16))) float sOut_[NPAR][kNWb][2][kCL * CW];  // [parity][wave][du | ddelta'][position][channel]
+    __shared__ float sdBC_[NPAR][kNWb][kWSb];                                       // [parity][wave] dB | dC of the wave's channels
     __shared__ int stab[4][kCL];                                                    // pixel positions of 4 chunks (ring)
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,6 +88,7 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         Anp = (v2f){a0, a1}; A2p = Anp * kLog2e;
     }
     const float Dv = (p.D != nullptr && sg == 0 && active) ? p.D[dsw] : 0.0f;       // D*g enters du once per channel, through group 0
+    // (D * dout added by the du store instead -- 4 FMAs per lane and chunk against 32 multiplies -- measured: no gain, +13 VGPRs)
     float bias4[PRE ? 1 : 4];
     if constexpr (!PRE) {
 #pragma unroll
@@ -149,35 +155,33 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
     float4 sig_prev = make_float4(1.f, 1.f, 1.f, 1.f);
     int len_prev = 0;
 
-    // the work of the PREVIOUS chunk (parity pp, positions tabp) that rides inside the sweeps of the current one.  GUARD = false: the
-    // previous chunk was full and all 8 channels of the wave exist -- no per-lane predicate, so the slices do not split the sweeps'
-    // basic block (a scheduling region ends at every exec-mask change: the sweeps of the steady state are ONE region)
-    auto store_du = [&](int pp, auto guard) {
+    // the work of the PREVIOUS chunk (out / dB|dC tiles of parity pp, positions tabp) that rides inside the sweeps of the current one
+    auto store_du = [&](int pp) {
         const float4 v = ld4b(sOut_[pp][wv][0] + pl * CW + q4);
-        if (!decltype(guard)::value || (pl < len_prev && quad_ok)) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
+        if (pl < len_prev && quad_ok) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
     };
-    auto store_dd = [&](int pp, auto guard) {
+    auto store_dd = [&](int pp) {
         float4 v = ld4b(sOut_[pp][wv][1] + pl * CW + q4);
         v.x *= sig_prev.x; v.y *= sig_prev.y; v.z *= sig_prev.z; v.w *= sig_prev.w;       // d delta = d delta' * softplus'
-        if (!decltype(guard)::value || (pl < len_prev && quad_ok)) {
+        if (pl < len_prev && quad_ok) {
             st4b(atb(ddb, __mul24(pos_prev, dd_sl) + q4), v);
             dbk[0] += v.x; dbk[1] += v.y; dbk[2] += v.z; dbk[3] += v.w;
         }
     };
-    auto flush_piece = [&](int pp, const int *tabp, int i, auto guard) {
+    auto flush_piece = [&](int pp, const int *tabp, int i) {
         const float *src = sdBC_[pp][0] + fsrc + 8 * i;
         const float v = (src[0] + src[kWSb]) + (src[2 * kWSb] + src[3 * kWSb]);
         const int l = flb0 + 8 * i;
-        if (!decltype(guard)::value || l < len_prev) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
+        if (l < len_prev) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
     };
-    using Guarded = std::integral_constant<bool, true>;
 
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
         const int par = ch & 1, len = min(kCL, L - ch * kCL);
         const bool have_prev = ch + 1 < n_chunks;
         float *sB = sBC[par][0], *sC = sBC[par][1];
-        float *su = sOut_[par][wv][0], *sgd = sOut_[par][wv][1];
-        float *sdB = sdBC_[par][wv], *sdC = sdBC_[par][wv] + kDCb;
+        const int po = W3 ? 0 : par, pp = W3 ? 0 : par ^ 1;        // tile parity of this chunk's results / of the previous chunk's
+        float *su = sOut_[po][wv][0], *sgd = sOut_[po][wv][1];
+        float *sdB = sdBC_[po][wv], *sdC = sdBC_[po][wv] + kDCb;
         // ---------------- stage chunk `ch` (prefetched one iteration ago) ----------------
         float4 sig_cur;
         {
@@ -212,43 +216,46 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         // dB / dC tiles (other parity) are combined below, (iii) the position table of chunk ch - 1 is written
         __syncthreads();
         if (ch > 0) prefetch(ch - 1);                      // lands while this chunk is computed
-        const int pp = par ^ 1;
         const int *tabp = stab[(ch + 1) & 3];
 
         // ---------------- packed sweeps (same algebra as scan_bwd.hip) ----------------
-        // FAST (the steady state: this chunk and the previous one full, all 8 channels present): no predicate anywhere -- one
-        // basic block.  Otherwise 4-position batches past the end of the sequence are skipped whole (they hold the scan identity:
-        // delta' = 0 -> a = 1, b = 0, dout = 0, so h, dh and every sum pass through them unchanged: bit-identical) and the previous
-        // chunk's slices are predicated.
-        auto sweeps = [&](auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        using G = std::integral_constant<bool, !FAST>;
-        v2f ap[kCL], ckp[NB];
+        // 4-position batches past the end of the sequence are skipped whole (wave-uniform branch): they hold the scan identity
+        // (delta' = 0 -> a = 1, b = 0, dout = 0), so h, dh and every sum pass through them unchanged -- bit-identical, and L = 49 / 196
+        // (MedMamba-T stages 3 / 2) do not pay for 15 / 28 padded positions.  (One unpredicated basic block for the steady state was
+        // measured as well, MS_BWD_FASTBLOCK in the history of this file: 3-4 % SLOWER -- the giant scheduling region raises the
+        // register pressure to 256 with spills; the per-batch regions the guards create schedule better.)
+        v2f ap[W3 ? 1 : kCL], ckp[NB];
         const float *sBl = sB + sg * 2, *sCl = sC + sg * 2;          // this lane's state pair inside a position row
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
-            if (FAST || kb * 4 < len) {
+            if (kb * 4 < len) {
 #pragma unroll
                 for (int l = kb * 4; l < kb * 4 + 4; ++l) {
                     if ((l & 3) == 0) ckp[l >> 2] = hp;
                     const v2f p1 = sP1[l * CW + c], p2 = sP2[l * CW + c];      // {delta', u}, {dout, delta' u}
                     const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPb);
-                    ap[l] = exp2_pk((v2f){p1.x, p1.x} * A2p);
-                    hp = pk_fma(ap[l], hp, (v2f){p2.y, p2.y} * Bp);
+                    const v2f a = exp2_pk((v2f){p1.x, p1.x} * A2p);
+                    if constexpr (!W3) ap[l] = a;
+                    hp = pk_fma(a, hp, (v2f){p2.y, p2.y} * Bp);
                 }
             }
-            if (FAST || have_prev) {                               // wave-uniform
-                if (kb == 1) store_du(pp, G());
-                if (kb == 3) store_dd(pp, G());
-                if (kb == 5) flush_piece(pp, tabp, 0, G());
-                if (kb == 7) flush_piece(pp, tabp, 1, G());
+            if (have_prev) {                                       // wave-uniform
+                if (kb == 1) store_du(pp);
+                if (kb == 3) store_dd(pp);
+                if (W3) {
+                    if (kb >= 4) flush_piece(pp, tabp, kb - 4);
+                } else {
+                    if (kb == 5) flush_piece(pp, tabp, 0);
+                    if (kb == 7) flush_piece(pp, tabp, 1);
+                }
             }
         }
+        if constexpr (W3) __syncthreads();     // every wave has read the previous chunk's dB / dC tiles: the reverse sweep may overwrite them
 #pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            if (FAST || lb < len) {
-                v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4];
+            if (lb < len) {
+                v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4], aj[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     Bp[j] = *reinterpret_cast<const v2f *>(sBl + (lb + j) * kRPb);
@@ -257,8 +264,9 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if constexpr (W3) aj[j] = exp2_pk((v2f){p1[j].x, p1[j].x} * A2p); else aj[j] = ap[lb + j];
                     bu[j] = (v2f){p2[j].y, p2[j].y} * Bp[j];
-                    hv[j] = pk_fma(ap[lb + j], j > 0 ? hv[j > 0 ? j - 1 : 0] : ckp[kb], bu[j]);
+                    hv[j] = pk_fma(aj[j], j > 0 ? hv[j > 0 ? j - 1 : 0] : ckp[kb], bu[j]);
                 }
                 float duv[4], ddv[4], vB8[8], vC8[8];
 #pragma unroll
@@ -270,9 +278,11 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                     const v2f qv = dhn * w;
                     const v2f t2 = qv * Anp;
                     dAp = pk_fma(qv, (v2f){p1[j].x, p1[j].x}, dAp);
-                    const v2f vb = dhn * (v2f){p2[j].y, p2[j].y}, vc = gg * hv[j];
-                    vB8[2 * j] = vb.x; vB8[2 * j + 1] = vb.y; vC8[2 * j] = vc.x; vC8[2 * j + 1] = vc.y;
-                    dhp = ap[lb + j] * dhn;
+                    // the dB / dC terms go to the DPP sums as separate scalars: plain v_mul_f32 with the scalar operand (a packed multiply
+                    // needs the splat in a register pair: two v_mov each, 96 per chunk in the ISA of the first version)
+                    vB8[2 * j] = dhn.x * p2[j].y; vB8[2 * j + 1] = dhn.y * p2[j].y;
+                    vC8[2 * j] = p2[j].x * hv[j].x; vC8[2 * j + 1] = p2[j].x * hv[j].y;
+                    dhp = aj[j] * dhn;
                     const float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
                     duv[j] = fmaf(s1, p1[j].x, Dv * p2[j].x);
                     ddv[j] = fmaf(s1, p1[j].y, s2);
@@ -287,23 +297,20 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                 sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
                 sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
             }
-            if (FAST || have_prev) {
-                if (kb == 5) flush_piece(pp, tabp, 2, G());
-                if (kb == 2) flush_piece(pp, tabp, 3, G());
+            if (!W3 && have_prev) {
+                if (kb == 5) flush_piece(pp, tabp, 2);
+                if (kb == 2) flush_piece(pp, tabp, 3);
             }
         }
-        };
-        if (MS_BWD_FASTBLOCK && have_prev && len == kCL && len_prev == kCL && nvalid == CW) sweeps(std::integral_constant<bool, true>());
-        else sweeps(std::integral_constant<bool, false>());
         sig_prev = sig_cur; pos_prev = pos_cur; len_prev = len;
     }
     // epilogue: chunk 0's stores and flush
     __syncthreads();
     {
         const int *tabp = stab[0];
-        store_du(0, Guarded()); store_dd(0, Guarded());
+        store_du(0); store_dd(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) flush_piece(0, tabp, i, Guarded());
+        for (int i = 0; i < 4; ++i) flush_piece(0, tabp, i);
     }
 
     if (active) {
@@ -352,8 +359,16 @@ int ss2d_bwd_launch(const MsScanBwdParams &q, int n_chunks, hipStream_t stream) 
     const MsScanParams &p = q.f;
     const int dpg = p.dim / p.n_groups, ncg = (dpg + 31) / 32;
     const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncg));
-    if (p.delta_softplus & MS_SCAN_DELTA_ACTIVATED) hipLaunchKernelGGL((ss2d_bwd_kernel<true>), grid, dim3(kNTb), 0, stream, q, n_chunks);
-    else hipLaunchKernelGGL((ss2d_bwd_kernel<false>), grid, dim3(kNTb), 0, stream, q, n_chunks);
+    static const int w3_env = [] { const char *e = getenv("MEDSCAN_BWD_W3"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool w3 = w3_env >= 0 ? w3_env == 1 : MS_BWD_W3_DEFAULT;
+    const bool pre = (p.delta_softplus & MS_SCAN_DELTA_ACTIVATED) != 0;
+    if (w3) {
+        if (pre) hipLaunchKernelGGL((ss2d_bwd_kernel<true, true>), grid, dim3(kNTb), 0, stream, q, n_chunks);
+        else hipLaunchKernelGGL((ss2d_bwd_kernel<false, true>), grid, dim3(kNTb), 0, stream, q, n_chunks);
+    } else {
+        if (pre) hipLaunchKernelGGL((ss2d_bwd_kernel<true, false>), grid, dim3(kNTb), 0, stream, q, n_chunks);
+        else hipLaunchKernelGGL((ss2d_bwd_kernel<false, false>), grid, dim3(kNTb), 0, stream, q, n_chunks);
+    }
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
