@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 7
+#define MEDSCAN_ABI_VERSION 8
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -349,6 +349,14 @@ int ms_gemm_bf16_bias_act(const void *A, int a_is_f32, int a_trans, int64_t lda,
  * dy fragment against an all-ones fragment) instead of a reduction pass of their own over dy. */
 int ms_gemm_bf16_wgrad_bias(const void *dy, int dy_is_f32, int64_t lddy, const void *x, int x_is_f32, int64_t ldx, float *dW, int64_t lddw,
                             float *dbias, int N, int K, int M, int k_splits, void *stream);
+
+/* The same products in the reference's own precision (it trains in fp32, train.py:57-77): `nn.Linear` / einsum of
+ * MedMamba.py:284,326,397,469,480 and their autograd on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32: fp32 products,
+ * fp32 accumulation) -- no hipBLASLt on the fp32 path.  A, B, C fp32; meaning of a_trans / b_trans / c_mode / k_splits as in
+ * ms_gemm_bf16 (c_mode 0, 2 or 3).  Built: (a_trans, b_trans) = (0,0) and (0,1) with c_mode 0 (+ bias / relu epilogue), (1,1) with
+ * c_mode 2 / 3 (zero C first).  lda / ldb multiples of 4, A and B 16-byte aligned. */
+int ms_gemm_f32(const float *A, int a_trans, int64_t lda, const float *B, int b_trans, int64_t ldb, float *C, int c_mode, int64_t ldc,
+                int M, int N, int K, int k_splits, const float *bias, int relu, void *stream);
 
 /* ---- bf16 working copies of the fp32 master weights, all in one launch ---------------------------------------------------
  * What torch.autocast does with one `_to_copy` launch per weight per forward (plus a layout copy per convolution weight on the

@@ -69,9 +69,16 @@ int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int 
                     float *scratch, int64_t npix, int C, hipStream_t s);
 int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
                        int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream);
+int gemm_f32_dispatch(const float *A, int a_trans, int64_t lda, const float *B, int b_trans, int64_t ldb, float *C, int c_mode, int64_t ldc,
+                      int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream);
 }  // namespace ms
 
 extern "C" {
+
+int ms_gemm_f32(const float *A, int a_trans, int64_t lda, const float *B, int b_trans, int64_t ldb, float *C, int c_mode, int64_t ldc,
+                int M, int N, int K, int k_splits, const float *bias, int relu, void *stream) {
+    return ms::gemm_f32_dispatch(A, a_trans, lda, B, b_trans, ldb, C, c_mode, ldc, M, N, K, k_splits, bias, relu, (hipStream_t)stream);
+}
 
 int ms_gemm_bf16(const void *A, int a_is_f32, int a_trans, int64_t lda, const void *B, int b_is_f32, int b_trans, int64_t ldb,
                  void *C, int c_mode, int64_t ldc, int M, int N, int K, int k_splits, void *stream) {

@@ -153,3 +153,82 @@ class _LinearMFMA(torch.autograd.Function):
 def linear_mfma(x, weight, out_fp32=False):
     """F.linear(x, weight) (no bias) on ms_gemm_bf16: bf16 MFMA with fp32 accumulation; bf16 result unless out_fp32."""
     return _LinearMFMA.apply(x, weight, out_fp32)
+
+
+# ---- fp32: the reference's own precision (it never uses autocast, train.py:57-77) on the exact-fp32 matrix instruction ----------
+def gemm_f32(a, b, a_trans=False, b_trans=False, out=None, accumulate=False, k_splits=1, bias=None, relu=False):
+    """C[i, j] (+)= sum_k Aop[i, k] * Bop[j, k] with fp32 operands, products and sums (ms_gemm_f32: v_mfma_f32_16x16x4_f32); a, b 2-D
+    row-major fp32 CUDA tensors with unit inner stride.  accumulate / k_splits > 1: fp32 atomics into a zero-initialised (or the given) C."""
+    _lib.require_cuda(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise RuntimeError("ms_gemm_f32: 2-D fp32 operands with unit inner stride")
+    M, K = (a.shape[1], a.shape[0]) if a_trans else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if b_trans else b.shape
+    if K != Kb:
+        raise RuntimeError(f"ms_gemm_f32: inner dimensions differ ({K} vs {Kb})")
+    c_mode = 2 if (accumulate or k_splits > 1) else 0
+    if out is None:
+        out = arena.zeros((M, N), a.device) if c_mode == 2 else torch.empty((M, N), device=a.device, dtype=torch.float32)
+    if out.stride(1) != 1 or tuple(out.shape) != (M, N) or out.dtype != torch.float32:
+        raise RuntimeError("ms_gemm_f32: bad output tensor")
+    with _lib.on_device(a.device):
+        _lib.check(_lib.lib().ms_gemm_f32(a.data_ptr(), int(a_trans), a.stride(0), b.data_ptr(), int(b_trans), b.stride(0), out.data_ptr(),
+                                          c_mode, out.stride(0), M, N, K, int(k_splits), bias.data_ptr() if bias is not None else None,
+                                          int(bool(relu)), _lib.current_stream_ptr(a.device)), "ms_gemm_f32")
+    return out
+
+
+def weight_grad_f32(dy, x, out=None):
+    """dW (N, K) (+)= dy^T @ x in fp32: split-K inside the kernel, the taller of (N, K) on the row side."""
+    N, K, M = dy.shape[1], x.shape[1], dy.shape[0]
+    if out is None:
+        out = arena.zeros((N, K), dy.device)
+    if N >= K:
+        return gemm_f32(dy, x, a_trans=True, b_trans=True, out=out, accumulate=True, k_splits=_k_splits(M, _blocks(N, K), N * K))
+    _lib.require_cuda(dy, x)
+    with _lib.on_device(dy.device):
+        _lib.check(_lib.lib().ms_gemm_f32(x.data_ptr(), 1, x.stride(0), dy.data_ptr(), 1, dy.stride(0), out.data_ptr(), 3, out.stride(0),
+                                          K, N, M, _k_splits(M, _blocks(K, N), N * K), None, 0, _lib.current_stream_ptr(dy.device)),
+                   "ms_gemm_f32")
+    return out
+
+
+def f32_rows_ok(t):
+    """rows the fp32 kernel can read in place: fp32, unit inner stride, row stride a multiple of 4 floats, 16-byte aligned."""
+    return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def _rows_f32(t):
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.dtype != torch.float32:
+        t2 = t2.float()
+    return t2 if f32_rows_ok(t2) else t2.contiguous()
+
+
+class _LinearF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        xm = _rows_f32(x)
+        w = weight.detach()
+        w = w if f32_rows_ok(w) else w.float().contiguous()
+        y = gemm_f32(xm, w)
+        ctx.save_for_backward(xm, w)
+        ctx.xshape, ctx.xdtype, ctx.wdtype = x.shape, x.dtype, weight.dtype
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, w = ctx.saved_tensors
+        dym = _rows_f32(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx = dy @ W as a plain / plain product against W^T (one small transposing copy of the weight): a transposed operand's
+            # fragments are four ds_read_b32 instead of one ds_read_b128, which made this product LDS-instruction bound (in_proj at
+            # stage 1: 137 -> see tools/bench_gemm_f32.py)
+            dx = gemm_f32(dym, w.t().contiguous()).view(ctx.xshape).to(ctx.xdtype)
+        return dx, weight_grad_f32(dym, xm).to(ctx.wdtype)
+
+
+def linear_f32(x, weight):
+    """F.linear(x, weight) (no bias) in fp32 on ms_gemm_f32 -- forward, input gradient and split-K weight gradient."""
+    return _LinearF32.apply(x, weight)

@@ -20,9 +20,9 @@ import torch
 
 from . import _lib, arena, shadow
 from ._lib import MsScanBwdParams, MsScanParams
-from .gemm_ops import gemm, weight_grad
+from .gemm_ops import gemm, gemm_f32, weight_grad, weight_grad_f32
 from .selective_scan_interface import TIMER, algorithmic_bytes
-from .ss2d_ops import _MFMA_GEMM, _MFMA_MIN_ROWS
+from .ss2d_ops import _F32_GEMM, _MFMA_GEMM, _MFMA_MIN_ROWS
 
 
 class _DWConvSiLUNHWC(torch.autograd.Function):
@@ -348,6 +348,8 @@ class _SS2DInner(torch.autograd.Function):
             wx = shadow.bf16(xproj_w).view(4 * C, D)       # cached bf16 copy, refreshed with all the others by one launch per step
         else:
             wx = (wx.to(mm_dtype) if (mm_dtype is not None and not mfma) else wx.float()).contiguous()
+        # fp32 runs (no autocast: the reference's precision): x_proj and its autograd on ms_gemm_f32, no library GEMM
+        f32mm = mm_dtype is None and not mfma and _F32_GEMM and D % 4 == 0 and (4 * C) % 4 == 0
         dev = xz.device
         xc = torch.empty((B, H, W, D), device=dev, dtype=torch.float32)
         y4 = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
@@ -362,7 +364,10 @@ class _SS2DInner(torch.autograd.Function):
                 proj = gemm(xc.view(M, D), wx)                                                               # (M, 4C) fp32
             else:
                 xm = xc.view(M, D).to(mm_dtype) if mm_dtype is not None else xc.view(M, D)
-                proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())
+                if f32mm:
+                    proj = gemm_f32(xm, wx)                                                                  # exact-fp32 MFMA kernel
+                else:
+                    proj = torch.mm(xm, wx.t(), out_dtype=torch.float32) if mm_dtype is not None else torch.mm(xm, wx.t())
             # inference (no gradient wanted): the Delta projection is formed inside the scan kernel (MS_SCAN_DT_FUSED) --
             # no dt_proj launch, no delta tensor, no saved states.  Training materialises delta: the backward kernel reads it.
             # `want_grad`: under torch.no_grad() `needs_input_grad` still mirrors the parameters' requires_grad, so the wrapper passes
@@ -395,7 +400,7 @@ class _SS2DInner(torch.autograd.Function):
         ctx.save_for_backward(xz, xc, xm if (mm_dtype is not None and not mfma) else None, wx, proj, delta, x_state, ysum, cw, cb, wdt,
                               A, Dv, bias, gamma, beta)
         ctx.geom = (N, R, float(eps))
-        ctx.mfma, ctx.act = mfma, act
+        ctx.mfma, ctx.act, ctx.f32mm = mfma, act, f32mm
         ctx.dtypes = (conv_w.dtype, conv_b.dtype if conv_b is not None else None, xproj_w.dtype, xproj_w.shape)
         return out
 
@@ -448,6 +453,9 @@ class _SS2DInner(torch.autograd.Function):
             if ctx.mfma:
                 dxe = gemm(dpm, wx, b_trans=True)                      # fp32 dproj read in place, fp32 result
                 dwx = weight_grad(dpm, xc.view(M, D))
+            elif ctx.f32mm:
+                dxe = gemm_f32(dpm, wx.t().contiguous())              # plain / plain against W^T (see gemm_ops._LinearF32)
+                dwx = weight_grad_f32(dpm, xc.view(M, D))
             elif xm is not None:
                 dpm = dpm.to(xm.dtype)
                 dxe = torch.mm(dpm, wx, out_dtype=torch.float32)
@@ -455,7 +463,7 @@ class _SS2DInner(torch.autograd.Function):
                 xm = xc.view(M, D)
                 dxe = torch.mm(dpm, wx)
             S = _split_k(M)
-            if ctx.mfma:
+            if ctx.mfma or ctx.f32mm:
                 pass
             elif S > 1:
                 a, b = dpm.view(S, M // S, 4 * C).transpose(1, 2), xm.view(S, M // S, D)

@@ -173,6 +173,8 @@ import os
 # the bf16-autocast projections run on the hand-written MFMA kernel (gemm_ops / csrc/gemm.hip); MEDSCAN_MFMA_GEMM=0 puts them
 # back on the BLAS library (kernel-variant experiments)
 _MFMA_GEMM = os.environ.get("MEDSCAN_MFMA_GEMM", "1") == "1"
+# fp32 runs: the projections on ms_gemm_f32 (v_mfma_f32_16x16x4_f32); MEDSCAN_F32_GEMM=0 keeps the library GEMMs (A/B runs)
+_F32_GEMM = os.environ.get("MEDSCAN_F32_GEMM", "1") == "1"
 # token-matrix height from which the MFMA kernel is used (below it the library GEMM wins in situ: measured)
 _MFMA_MIN_ROWS = int(os.environ.get("MEDSCAN_MFMA_MIN_ROWS", "0"))
 
@@ -187,6 +189,10 @@ def linear_splitk(x, weight, out_fp32=False):
         from .gemm_ops import linear_mfma
         with torch.autocast(device_type="cuda", enabled=False):
             return linear_mfma(x, weight, out_fp32)
+    if (_MFMA_GEMM and _F32_GEMM and x.is_cuda and not torch.is_autocast_enabled() and x.dtype == torch.float32
+            and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0):
+        from .gemm_ops import linear_f32           # fp32 runs (the reference's precision): exact-fp32 MFMA kernel, no library GEMM
+        return linear_f32(x, weight)
     if x.is_cuda and (x.numel() // x.shape[-1] >= 8192 or (torch.is_autocast_enabled() and x.requires_grad)):
         return _LinearSplitK.apply(x, weight, out_fp32)
     y = torch.nn.functional.linear(x, weight)

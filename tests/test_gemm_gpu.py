@@ -142,3 +142,92 @@ def test_weight_gradient_with_bias_gradient_in_one_launch(cfg, dy_f32):
     weight_grad(dy, x, out=dw, dbias=db)
     np.testing.assert_allclose(db.cpu().numpy(), 2 * want_b.cpu().numpy(), rtol=1e-4, atol=2e-4 * float(want_b.abs().max()))
     np.testing.assert_allclose(dw.cpu().numpy(), 2 * want_w.cpu().numpy(), rtol=1e-4, atol=2e-4 * float(want_w.abs().max()))
+
+
+# ---- ms_gemm_f32: the same products in the reference's own precision (exact fp32 MFMA) -------------------------------------------
+F32_SHAPES = [(3136 * 2, 192, 48), (784 * 2, 152, 192), (196 * 2, 768, 192), (49 * 2, 384, 768), (200, 140, 96), (129, 68, 40),
+              (1, 4, 8), (1000, 48, 96), (256, 224, 768), (77, 36, 100), (3136 * 8, 140, 96)]
+
+
+@pytest.mark.parametrize("shape", F32_SHAPES, ids=[f"{s[0]}x{s[1]}x{s[2]}" for s in F32_SHAPES])
+def test_f32_gemm_all_products_vs_float64(shape):
+    """ms_gemm_f32 (v_mfma_f32_16x16x4_f32: fp32 products, fp32 accumulation) against float64 products of the same fp32 operands:
+    forward y = x W^T, input gradient dx = dy W, split-K weight gradient dW = dy^T x in both orientations, the bias + ReLU epilogue,
+    strided rows.  Tolerance: fp32 accumulation over K (resp. M) terms, 4e-6 x sqrt(terms / 64) of the result's magnitude."""
+    from medical_image_classification_amd.gemm_ops import gemm_f32, weight_grad_f32
+    M, N, K = shape
+    gen = torch.Generator(device=dev()).manual_seed(M + 7 * N + K)
+    Kp, Np = (K + 3) // 4 * 4 + 4, (N + 3) // 4 * 4         # row strides: multiples of 4 floats, wider than the rows (strided views)
+    xa = torch.randn(M, Kp, device=dev(), generator=gen)
+    x = xa[:, :K]
+    w = (torch.randn(N, Kp, device=dev(), generator=gen) * K ** -0.5)[:, :K]
+    bias = torch.randn(N, device=dev(), generator=gen)
+    tol = lambda ref, terms: 4e-6 * max(1.0, (terms / 64) ** 0.5) * float(ref.abs().max())
+    y = gemm_f32(x, w)
+    ref = x.double() @ w.double().t()
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=tol(ref, K))
+    yb = gemm_f32(x, w, bias=bias, relu=True)
+    refb = torch.relu(ref + bias.double())
+    np.testing.assert_allclose(yb.double().cpu().numpy(), refb.cpu().numpy(), rtol=0, atol=tol(ref, K))
+    dy = torch.randn(M, Np + 4, device=dev(), generator=gen)[:, :N]
+    if N % 4 == 0:
+        dx = gemm_f32(dy, w.contiguous() if K % 4 else w, b_trans=True)
+        refx = dy.double() @ w.double()
+        np.testing.assert_allclose(dx.double().cpu().numpy(), refx.cpu().numpy(), rtol=0, atol=tol(refx, N))
+    if M % 4 == 0 and N % 4 == 0 and K % 4 == 0:
+        refw = dy.double().t() @ x.double()
+        for flip in (False, True):                            # both orientations of the split-K weight gradient
+            if flip:
+                dwt = weight_grad_f32(x, dy)                  # (K, N) = x^T dy
+                np.testing.assert_allclose(dwt.double().cpu().numpy(), refw.t().cpu().numpy(), rtol=0, atol=tol(refw, M))
+            else:
+                dw = weight_grad_f32(dy, x)
+                np.testing.assert_allclose(dw.double().cpu().numpy(), refw.cpu().numpy(), rtol=0, atol=tol(refw, M))
+
+
+def test_f32_gemm_rejects_what_it_does_not_build():
+    from medical_image_classification_amd import _lib
+    lib = _lib.lib()
+    a = torch.zeros(8, 8, device=dev()); st = _lib.current_stream_ptr(dev())
+    p = a.data_ptr()
+    assert lib.ms_gemm_f32(None, 0, 8, p, 0, 8, p, 0, 8, 8, 8, 8, 1, None, 0, st) == -1          # NULL
+    assert lib.ms_gemm_f32(p, 0, 8, p, 0, 8, p, 1, 8, 8, 8, 8, 1, None, 0, st) == -2             # c_mode 1 (bf16 store) does not exist here
+    assert lib.ms_gemm_f32(p, 0, 8, p, 0, 8, p, 0, 8, 8, 8, 8, 2, None, 0, st) == -2             # split-K needs an accumulating mode
+    assert lib.ms_gemm_f32(p, 1, 8, p, 0, 8, p, 2, 8, 8, 8, 8, 1, None, 0, st) == -6             # (transposed, plain) is not built
+    assert lib.ms_gemm_f32(p, 0, 6, p, 0, 8, p, 0, 8, 8, 8, 8, 1, None, 0, st) == -4             # lda not a multiple of 4
+    assert lib.ms_gemm_f32(p + 4, 0, 8, p, 0, 8, p, 0, 8, 8, 8, 4, 1, None, 0, st) == -4         # unaligned base
+
+
+def test_f32_linear_autograd_matches_f_linear_and_fp32_model_uses_it(monkeypatch):
+    """linear_splitk without autocast = ms_gemm_f32 forward / dx / dW (vs F.linear autograd in float64); and an fp32 SS2D block runs
+    NO library GEMM at all (the x_proj of the one-node inner path included): aten mm / addmm / bmm never dispatched."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from medical_image_classification_amd import medmamba as mm
+    from medical_image_classification_amd.ss2d_ops import linear_splitk
+    torch.manual_seed(4)
+    x = torch.randn(3, 14, 14, 96, device=dev(), requires_grad=True)
+    w = (torch.randn(192, 96, device=dev()) * 0.1).requires_grad_()
+    g = torch.randn(3, 14, 14, 192, device=dev())
+    y = linear_splitk(x, w)
+    y.backward(g)
+    xr, wr = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    yr = torch.nn.functional.linear(xr, wr)
+    yr.backward(g.double())
+    for got, want in ((y, yr), (x.grad, xr.grad), (w.grad, wr.grad)):
+        np.testing.assert_allclose(got.detach().double().cpu().numpy(), want.detach().cpu().numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+
+    class Audit(TorchDispatchMode):
+        def __init__(self):
+            super().__init__(); self.seen = []
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            n = func.__name__.split(".")[0]
+            if n in ("mm", "addmm", "bmm", "baddbmm", "matmul", "linear"):
+                self.seen.append(n)
+            return func(*args, **(kwargs or {}))
+
+    blk = mm.SS2D(d_model=48).to(dev())
+    xi = torch.randn(2, 14, 14, 48, device=dev(), requires_grad=True)
+    with Audit() as a:
+        out = blk(xi)
+        out.sum().backward()
+    assert not a.seen, a.seen
