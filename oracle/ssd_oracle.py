@@ -40,6 +40,32 @@ def ssd_scan_ref(x, dt, A, B, C, D=None, dt_bias=None, dt_softplus=False):
     return y.to(x.dtype)
 
 
+def ssd_scan_by_expansion(x, dt, A, B, C, D=None, dt_bias=None, dt_softplus=False):
+    """The same operator evaluated by the PINNED S6 oracle (oracle/scan_oracle.c through its autograd front-end) with every
+    scalar-A head expanded to diagonal A: channel d = (head, p), A[d, :] = A[head], delta[d] = dt[head], B / C groups shared by
+    h / g heads -- the identity of SURVEY.md 8(a) row a22, which tests/test_ssd_cpu.py holds to `ssd_scan_ref` (output and all
+    gradients).  fp32, C / OpenMP: what makes an oracle run at 224 x 224 (L = 3136) affordable; differentiable."""
+    from .scan_oracle import selective_scan_oracle
+    b, l, h, p = x.shape
+    g, n = B.shape[2], B.shape[3]
+    dim = h * p
+    u = x.float().reshape(b, l, dim).permute(0, 2, 1)
+    delta = dt.float().unsqueeze(-1).expand(b, l, h, p).reshape(b, l, dim).permute(0, 2, 1)
+    A6 = A.float().view(h, 1, 1).expand(h, p, n).reshape(dim, n)
+    D6 = None
+    if D is not None:
+        D6 = D.float().reshape(dim) if D.dim() == 2 else D.float().view(h, 1).expand(h, p).reshape(dim)
+    b6 = dt_bias.float().view(h, 1).expand(h, p).reshape(dim) if dt_bias is not None else None
+    y = selective_scan_oracle(u.contiguous(), delta.contiguous(), A6.contiguous(), B.float().permute(0, 2, 3, 1).contiguous(),
+                              C.float().permute(0, 2, 3, 1).contiguous(), D6.contiguous() if D6 is not None else None, None,
+                              b6.contiguous() if b6 is not None else None, dt_softplus)
+    return y.permute(0, 2, 1).reshape(b, l, h, p).to(x.dtype)
+
+
+# tests at full image sizes switch the module oracles below to the expansion (install_ssd(model, by_expansion=True))
+_SCAN = {"fn": ssd_scan_ref}
+
+
 def rmsnorm_gated_ref(x, z, weight, eps=1e-5, norm_before_gate=False):
     x = x.double()
     if z is not None and not norm_before_gate:
@@ -70,8 +96,8 @@ def ss2d_ssd_forward_oracle(mod, u):
     Cs = Cs.reshape(B, -1, L).permute(0, 2, 1).reshape(B, L, mod.ngroups, -1)
     As = -torch.exp(mod.A_logs.float())
     Ds = mod.Ds.view(-1, mod.headdim) if mod.D_has_hdim else mod.Ds
-    y = ssd_scan_ref(xs.float(), dts.float(), As, Bs.float(), Cs.float(), D=Ds, dt_bias=mod.dt_bias.view(-1),
-                     dt_softplus=True)
+    y = _SCAN["fn"](xs.float(), dts.float(), As, Bs.float(), Cs.float(), D=Ds, dt_bias=mod.dt_bias.view(-1),
+                    dt_softplus=True)
     out_y = y.reshape(B, L, K, -1).permute(0, 2, 3, 1)                                 # (B,4,d_ssm,L)
     inv_y = out_y[:, 2:4].flip(-1)
     wh_y = out_y[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L)
@@ -99,8 +125,8 @@ def _ssd_core_oracle(mod, xBCdt_nchw, z, z0, x0, d_mlp, B, H, W):
     Cs = Cs.reshape(B, -1, L).permute(0, 2, 1).reshape(B, L, mod.ngroups, -1)
     As = -torch.exp(mod.A_logs.float())
     Ds = mod.Ds.view(-1, mod.headdim) if mod.D_has_hdim else mod.Ds
-    y = ssd_scan_ref(xs.float(), dts.float(), As, Bs.float(), Cs.float(), D=Ds, dt_bias=mod.dt_bias.view(-1),
-                     dt_softplus=True)
+    y = _SCAN["fn"](xs.float(), dts.float(), As, Bs.float(), Cs.float(), D=Ds, dt_bias=mod.dt_bias.view(-1),
+                    dt_softplus=True)
     out_y = y.reshape(B, L, K, -1).permute(0, 2, 3, 1)
     inv_y = out_y[:, 2:4].flip(-1)
     wh_y = out_y[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L)
@@ -132,9 +158,12 @@ def crossmamba_forward_oracle(mod, u1, u2, u2_cat_u1, u1_cat_u2):
     return one(u1, u2_cat_u1), one(u2, u1_cat_u2)
 
 
-def install_ssd(model):
-    """Rebind every SS2D_with_SSD and CrossMamba in `model` to the CPU restatement (CPU-side checker of the GPU modules)."""
+def install_ssd(model, by_expansion=False):
+    """Rebind every SS2D_with_SSD and CrossMamba in `model` to the CPU restatement (CPU-side checker of the GPU modules).
+    by_expansion: the scans of `_ssd_core_oracle` (CrossMamba, and the SS_Conv_SSD blocks routed through it) run on the pinned
+    C oracle by expansion instead of the float64 Python loop -- process-wide until the next install_ssd call."""
     import types
+    _SCAN["fn"] = ssd_scan_by_expansion if by_expansion else ssd_scan_ref
     from medical_image_classification_amd.cnn_mamba import SS2D_with_SSD
     from medical_image_classification_amd.crossmamba import CrossMamba
     for m in model.modules():

@@ -497,3 +497,46 @@ def test_ssd_backward_all_slices_in_one_launch(cfg, monkeypatch):
     assert torch.equal(ya, yb)
     for a, b, name in zip(ga, gb, ("dxc", "dA", "dD", "dbias")):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(b.abs().max()), err_msg=name)
+
+
+def test_vfefm_224_batch4_matches_cpu_oracle():
+    """BASELINE.json configs[4]'s geometry -- two 3 x 224 x 224 modalities, batch 4 -- on a depth-reduced VFEFM (one block per
+    stage, dims 64..512, d_state 16: every scan at its full-size sequence lengths 3136 / 784 / 196 / 49, which is what the toy 64 x 64
+    test cannot exercise): fused image, loss and > 60 parameter gradients against the CPU oracle modules, whose SSD scans run on the
+    pinned C S6 oracle by expansion (tests/test_ssd_cpu.py holds that to the float64 loop).  fp32 on both sides.  PARITY UNPINNED
+    against the reference's Triton dependency."""
+    from medical_image_classification_amd.crossmamba import VFEFM
+    from medical_image_classification_amd.fusion_loss import FusionLoss
+    cfg = dict(depths=[1, 1, 1, 1], dims=[64, 128, 256, 512], depths_decoder=[1, 1, 1, 1], dims_decoder=[512, 256, 128, 64],
+               d_state=16, drop_path_rate=0.0)
+    torch.manual_seed(12)
+    net, ref = VFEFM(**cfg), VFEFM(**cfg)
+    ref.load_state_dict(net.state_dict())
+    ssd_oracle.install_ssd(ref, by_expansion=True)
+    try:
+        net.to(dev()).train(); ref.train()
+        x1, x2 = torch.rand(4, 3, 224, 224), torch.rand(4, 3, 224, 224)
+        out_r = ssd_oracle.vfefm_forward_oracle(ref, x1, x2)
+        out_d = net(x1.to(dev()), x2.to(dev()))
+        assert tuple(out_d.shape) == (4, 1, 224, 224)
+        close(out_d, out_r, 3e-3, "fused image")
+        crit = FusionLoss()
+        lr_ = crit(x1, x2, out_r.clamp(0, 1))[0]
+        ld_ = crit.to(dev())(x1.to(dev()), x2.to(dev()), out_d.clamp(0, 1))[0]
+        lr_.backward(); ld_.backward()
+        assert abs(float(ld_.detach()) - float(lr_.detach())) <= 1e-3 * max(1.0, abs(float(lr_.detach())))
+        pr = dict(ref.named_parameters())
+        checked = 0
+        for k, p in net.named_parameters():
+            if pr[k].grad is None:
+                assert p.grad is None, k
+                continue
+            if ("fusion" in k or "self_attention" in k or "final" in k or "in_proj" in k) and "norm" not in k:
+                a, r = p.grad.detach().cpu().double().flatten(), pr[k].grad.double().flatten()
+                cos = float(a @ r / (a.norm() * r.norm()).clamp_min(1e-300))
+                rel = float((a - r).norm() / r.norm().clamp_min(1e-300))
+                assert cos >= 0.999 and rel <= 5e-2, (k, cos, rel)       # fp32 vs fp32, atomics-ordered sums over 4 x 3136 positions; 4-element vectors (A_logs) included
+                checked += 1
+        assert checked > 60
+    finally:
+        ssd_oracle.install_ssd(torch.nn.Module())          # back to the float64 loop for the other tests of this process
