@@ -30,7 +30,7 @@ import torch.utils.checkpoint as checkpoint
 from .efficient_scan import cross_selective_scan, cross_selective_scan_cross
 from .medmamba import DropPath
 
-_UNBUILT = ("v0", "v0_seq", "share_ssm", "share_a")
+_STUBS = ("share_ssm", "share_a")      # cores whose reference bodies are `...` (cross.py:697-707): nothing to build
 
 
 class _S6Mixer(nn.Module):
@@ -54,9 +54,12 @@ class _S6Mixer(nn.Module):
             forward_type, self.out_norm = forward_type[:-len("sigmoid")], nn.Sigmoid()
         else:
             self.out_norm = nn.LayerNorm(d_inner)
-        if forward_type in _UNBUILT:
-            raise NotImplementedError(f"forward_type {forward_type!r}: only the stride-2 scan cores 'v1' / 'v2' are built (cross.py:709-722)")
-        self.K = self.K2 = 4
+        # cores (cross.py:475-485): v1 / v2 = the stride-2 scan; v0 / v0_seq = the full-resolution four-direction scan of VMamba v0
+        # (= MedMamba's forward_corev0 followed by out_norm), built on this package's SS2D scan core; share_ssm / share_a are `...` in
+        # the reference (they return None): their parameter shapes (K, K2) are kept, calling them raises
+        self.core_type = forward_type if forward_type in ("v0", "v0_seq", "v1", "v2") + _STUBS else "v2"
+        self.K = 1 if forward_type == "share_ssm" else 4
+        self.K2 = 1 if forward_type == "share_a" else self.K
         if self.d_conv > 1:
             self.conv2d = nn.Conv2d(d_expand, d_expand, groups=d_expand, bias=conv_bias, kernel_size=d_conv, padding=(d_conv - 1) // 2)
         self.ssm_low_rank = d_inner < d_expand
@@ -118,6 +121,31 @@ class _S6Mixer(nn.Module):
         d._no_weight_decay = True
         return d
 
+    def forward_corev0(self, x, to_dtype=False, channel_first=False, **_ignored):
+        """cross.py:598-646: cross-scan (4 directions at full resolution) -> x_proj / dt_proj -> selective scan -> cross-merge ->
+        out_norm; here on the SS2D addressing mode of the scan kernels (nothing is permuted or copied).  The reference's own forward()
+        cannot reach this core -- it passes `step_size=`, which the v0 signatures do not take (TypeError at cross.py:732) -- so extra
+        keywords are accepted and ignored; called directly, as the reference allows, the behaviour is the same."""
+        from .ss2d_fused import ss2d_core
+        if channel_first:
+            x = x.permute(0, 2, 3, 1)
+        B, H, W, D = x.shape
+        y = ss2d_core(x.contiguous().float(), self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
+                      self.d_state, self.dt_rank)                                  # (B, H, W, D) merged, fp32
+        y = self.out_norm(y.view(B, H * W, D)).view(B, H, W, -1)                   # LayerNorm over channels (Softmax: over dim 1 = L)
+        return y.to(x.dtype) if to_dtype else y
+
+    # one selective_scan_fn call per direction in the reference (cross.py:648-695): the same function of the same operands.  (The
+    # reference's own v0_seq cannot run: its wrapper passes delta_bias in selective_scan_fn's `z` slot, cross.py:650.)
+    forward_corev0_seq = forward_corev0
+
+    def _forward_core_stub(self, *a, **k):
+        raise NotImplementedError(f"forward_type {self.core_type!r}: the reference's body is `...` (cross.py:697-707)")
+
+    def _pick_core(self, v2):
+        return {"v0": self.forward_corev0, "v0_seq": self.forward_corev0_seq, "share_ssm": self._forward_core_stub,
+                "share_a": self._forward_core_stub}.get(self.core_type, v2)
+
     def _conv_act(self, x, act):
         """(b,h,w,d) -> act(conv2d(x)) as (b,d,h,w) (cross.py:731-732)."""
         return act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
@@ -136,7 +164,7 @@ class SS2D(_S6Mixer):
         self.act = act_layer()
         self._build(d_model, d_state, ssm_ratio, ssm_rank_ratio, dt_rank, d_conv, conv_bias, dropout, bias, dt_min, dt_max, dt_init,
                     dt_scale, dt_init_floor, simple_init, forward_type, step_size)
-        self.forward_core = self.forward_corev2
+        self.forward_core = self._pick_core(self.forward_corev2)
 
     def forward_corev2(self, x, nrows=-1, channel_first=False, step_size=2):
         if not channel_first:

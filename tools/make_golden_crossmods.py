@@ -22,7 +22,8 @@ ext = sys.modules["selective_scan_cuda"]
 
 
 def _fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus):
-    return [ssi.selective_scan_ref(u, delta, A, B, C, D, z, delta_bias, delta_softplus), torch.zeros(1)]
+    # x: the (batch, dim, n_chunks, 2 * dstate) checkpoint tensor of the CUDA extension; SelectiveScanFn.forward slices it for last_state
+    return [ssi.selective_scan_ref(u, delta, A, B, C, D, z, delta_bias, delta_softplus), torch.zeros(u.shape[0], u.shape[1], 1, 2 * A.shape[1])]
 
 
 def _bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute):
@@ -64,3 +65,27 @@ dump("ss2d_nozact_lowrank_8x8", cross.SS2D(d_model=16, d_state=3, ssm_ratio=2.0,
 dump("ss2d_cross_d12_6x7", cross.SS2D_cross_new(d_model=12, d_state=4), [torch.randn(2, 6, 7, 12), torch.randn(2, 6, 7, 12)])
 dump("vssblock_new_d16_6x6", cross.VSSBlock_new(hidden_dim=16, ssm_d_state=4, mlp_ratio=2.0), [torch.randn(2, 6, 6, 16)])
 dump("vssblock_cross_d16_5x8", cross.VSSBlock_Cross_new(hidden_dim=16, d_state=4), [torch.randn(1, 5, 8, 16), torch.randn(1, 5, 8, 16)])
+
+
+def dump_core(tag, mod, x):
+    """forward_corev0 CALLED DIRECTLY (the reference's forward() cannot reach it: it passes `step_size=`, which the v0 signatures do
+    not take, cross.py:732 vs :598): y, dx and the core's parameter gradients.  forward_corev0_seq cannot run at all in the reference:
+    its local wrapper hands (.., D, delta_bias, delta_softplus) positionally to selective_scan_fn, whose seventh parameter is `z`
+    (cross.py:650 vs selective_scan_interface.py:83) -- a TypeError here, a shape error under the CUDA extension."""
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.endswith("Ds") or "norm" in n:
+                p.add_(torch.randn_like(p) * 0.2)
+    xi = x.clone().requires_grad_()
+    y = mod.forward_corev0(xi)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    out = {f"sd.{k}": v.detach().numpy() for k, v in mod.state_dict().items()}
+    out.update(x0=x.numpy(), dx0=xi.grad.numpy(), y=y.detach().numpy(), gy=gy.numpy())
+    out.update({f"grad.{n}": p.grad.numpy() for n, p in mod.named_parameters() if p.grad is not None})
+    np.savez_compressed(os.path.join(mg.OUT, f"crosscore_{tag}.npz"), **{k: np.asarray(v) for k, v in out.items()})
+    print(tag, "y", tuple(y.shape), "params with grad", sum(1 for p in mod.parameters() if p.grad is not None))
+
+
+dump_core("v0_d12_5x6", cross.SS2D(d_model=12, d_state=4, forward_type="v0"), torch.randn(2, 5, 6, 24))
+dump_core("v0_d16_7x4", cross.SS2D(d_model=16, d_state=5, forward_type="v0"), torch.randn(1, 7, 4, 32))
