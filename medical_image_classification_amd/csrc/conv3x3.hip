@@ -41,7 +41,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // -- not the MFMAs, not LDS -- were the kernel's time.)  Slices of 32 channels use v_mfma_f32_16x16x32_bf16 (one ds_read_b128 per
 // fragment), a 16-channel tail slice the K = 16 form.
 template <int NB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_CONV_WAVES, MS_CONV_WAVES)))
+// (NB = 4, MedMamba-B's 64-channel blocks: 60 KB of LDS and 3 x 16 accumulator registers more -- two workgroups per CU is what fits)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB >= 4 ? 2 : MS_CONV_WAVES, NB >= 4 ? 2 : MS_CONV_WAVES)))
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
                     int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img) {
     __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kXP];
