@@ -12,6 +12,7 @@
 // group sg, channel c); workgroup = the waves that share a 128-byte line (32 channels).
 // Everything else (reference (B,D,L) layout, other d_state, scalar-decay SSD forms, unaligned tensors) runs on the
 // general kernels of scan_fwd.hip / scan_bwd.hip.
+#include <cstdlib>
 #include <type_traits>
 #include "scan_common.h"
 
@@ -319,7 +320,8 @@ int ss2d_fwd_launch(const MsScanParams &p, int n_chunks, hipStream_t stream) {
     const dim3 grid((unsigned)((int64_t)p.batch * p.n_groups * ncg));
     const bool dtf = (p.delta_softplus & MS_SCAN_DT_FUSED) != 0;
     // 8-channel waves (8 state groups, 2 states per lane) when 16-channel waves would leave the chip under-filled
-    const bool cw8 = (int64_t)p.batch * p.n_groups * ncg * 2 < 2048;
+    static const int cw_env = [] { const char *e = getenv("MEDSCAN_FWD_CW"); return e ? atoi(e) : 0; }();      // experiments: force 8 / 16
+    const bool cw8 = cw_env ? cw_env == 8 : (int64_t)p.batch * p.n_groups * ncg * 2 < 4096;      // measured (MedMamba-T bs 64): stage 1 (3072 16-channel waves) 177 vs 190 us with 8-channel waves; stage 2 (6144) equal
     if (cw8) {
         if (dtf) hipLaunchKernelGGL((ss2d_fwd_kernel<8, true>), grid, dim3(256), 0, stream, p, n_chunks);
         else     hipLaunchKernelGGL((ss2d_fwd_kernel<8, false>), grid, dim3(256), 0, stream, p, n_chunks);
