@@ -10,7 +10,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter: continue
             name = r["Kernel_Name"]
-            key = "scan_bwd" if "scan_bwd_kernel" in name else "scan_fwd" if ("scan_fwd_kernel" in name or "ss2d_fwd_kernel" in name) else None
+            key = "scan_bwd" if ("scan_bwd_kernel" in name or "ss2d_bwd_kernel" in name) else "scan_fwd" if ("scan_fwd_kernel" in name or "ss2d_fwd_kernel" in name) else None
             if key: acc[key][0] += float(r["Counter_Value"]); acc[key][1] += 1
     return acc
 fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
