@@ -94,6 +94,10 @@ typedef enum MsStatus {
                                 ms_dtproj_bwd); MsScanBwdParams.ddt_x / ddt_w are reserved for that backward (same addressing
                                 as dB / (dim, dt_rank), accumulated) and are ignored today. */
 
+#define MS_SCAN_DELTA_OUT 1024 /* with MS_SCAN_DT_FUSED (forward): `delta` is an OUTPUT -- the kernel stores delta' = softplus(dt_x . dt_w + bias) there
+                                (same addressing as the input form), which is what the TRAINING path hands to the backward launch as
+                                MS_SCAN_DELTA_ACTIVATED input: the Delta projection of MedMamba.py:400,403-405 then has no forward launch
+                                and no pre-activation tensor at all. */
 #define MS_SCAN_DELTA_ACTIVATED 512  /* with MS_SCAN_SOFTPLUS: `delta` already holds delta' = softplus(raw + delta_bias) (ms_dtproj_fwd_act writes
                                 it: the projection kernel is bandwidth-bound, the scan kernels are issue-bound, so the ~13 instructions of
                                 the activation per element sit better there).  Forward and backward use it as is; the backward still

@@ -128,6 +128,8 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
     const int c0s = nvalid > 0 ? c0w : 0;                       // a wave past the last channel block loads the group's first channels (in bounds) and stores nothing
     const float *ub = p.u + b * p.u_batch_stride + g * p.u_group_stride + c0s;
     const float *db = DTF ? nullptr : p.delta + b * p.delta_batch_stride + g * p.delta_group_stride + c0s;
+    // MS_SCAN_DELTA_OUT: the fused projection's delta' is also stored (for the backward launch of a training step)
+    float *dob = (DTF && (p.delta_softplus & MS_SCAN_DELTA_OUT) && p.delta) ? const_cast<float *>(p.delta) + b * p.delta_batch_stride + g * p.delta_group_stride + c0s : nullptr;
     float *ob = p.out + b * p.out_batch_stride + g * p.out_group_stride + c0s;
     const float *Bb = p.B + b * p.B_batch_stride + g * p.B_group_stride;
     const float *Cb = p.C + b * p.C_batch_stride + g * p.C_group_stride;
@@ -223,6 +225,7 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
                 us[j] = ok ? uu[j] : 0.0f;
             }
             uk[k] = make_float4(us[0], us[1], us[2], us[3]);
+            if (DTF && dob != nullptr && ok) st4(at(dob, __mul24(spos[ch & 1][pl], dl_sl) + my4), make_float4(dl[0], dl[1], dl[2], dl[3]));
             float *dst = reinterpret_cast<float *>(sdd + pl * CW + my4);
             st4(dst, make_float4(dl[0], dl[0] * us[0], dl[1], dl[1] * us[1]));
             st4(dst + 4, make_float4(dl[2], dl[2] * us[2], dl[3], dl[3] * us[3]));
@@ -304,11 +307,12 @@ bool ss2d_fast_ok(const MsScanParams &p) {
     const bool dtf = (p.delta_softplus & MS_SCAN_DT_FUSED) != 0;
     if (dtf && (p.dt_rank < 1 || p.dt_rank > kMaxR || !p.dt_x || !p.dt_w)) return false;
     if (!dtf && !p.delta) return false;
+    if ((p.delta_softplus & MS_SCAN_DELTA_OUT) && !(dtf && p.delta)) return false;
     auto act_ok = [](const float *ptr, int64_t sb, int64_t sgp, int64_t sl) {
         return aligned16(ptr) && sb % 4 == 0 && sgp % 4 == 0 && sl % 4 == 0 && fits24(sl);
     };
     if (!act_ok(p.u, p.u_batch_stride, p.u_group_stride, p.u_l_stride)) return false;
-    if (!dtf && !act_ok(p.delta, p.delta_batch_stride, p.delta_group_stride, p.delta_l_stride)) return false;
+    if ((!dtf || (p.delta_softplus & MS_SCAN_DELTA_OUT)) && !act_ok(p.delta, p.delta_batch_stride, p.delta_group_stride, p.delta_l_stride)) return false;
     if (!fits24(p.B_l_stride) || !fits24(p.C_l_stride) || !fits24(p.seqlen)) return false;
     return true;
 }

@@ -106,6 +106,10 @@ def _split_k(M):
 
 
 _DT_ACT = os.environ.get("MEDSCAN_DT_ACTIVATED", "1") == "1"
+# training forward: delta' formed inside the scan kernel and stored for the backward (MS_SCAN_DELTA_OUT; no ms_dtproj_fwd_act launch).
+# Measured on MI355X (MedMamba-T bs 64): 17.037 vs 17.039 ms per step -- the R FMAs + softplus per element that move into the
+# issue-bound forward scan cost what the 8 projection launches cost -- so it stays opt-in (parity: test_modules_gpu with =1)
+_DT_FUSED_TRAIN = os.environ.get("MEDSCAN_DT_FUSED_TRAIN", "0") == "1"
 
 
 def _dtproj_fwd(proj, wdt, B, L, D, R, C, act_bias=None):
@@ -373,16 +377,26 @@ class _SS2DInner(torch.autograd.Function):
             # `want_grad`: under torch.no_grad() `needs_input_grad` still mirrors the parameters' requires_grad, so the wrapper passes
             # whether a graph is being recorded at all (the validation loop of train.py:82-95 is eval() + no_grad())
             need_bwd = want_grad and any(ctx.needs_input_grad)
-            fuse_dt = (not need_bwd) and N == 16 and R <= 32 and D % 4 == 0
-            act = (not fuse_dt) and _dt_act_ok(R)          # delta' = softplus(delta + bias) formed by the projection kernel
-            delta = None if fuse_dt else _dtproj_fwd(proj, wdt, B, L, D, R, C, act_bias=bias if act else None)
+            fusable = N == 16 and R <= 32 and D % 4 == 0
+            fuse_dt = (not need_bwd) and fusable
+            # training: the forward scan forms delta' itself AND stores it for the backward launch (MS_SCAN_DELTA_OUT): no dt_proj
+            # forward launch, no pre-activation tensor (MedMamba.py:400,403-405)
+            fuse_dt_train = need_bwd and fusable and _DT_FUSED_TRAIN and _dt_act_ok(R)
+            act = fuse_dt_train or ((not fuse_dt) and _dt_act_ok(R))   # delta' = softplus(delta + bias) reaches the backward activated
+            if fuse_dt_train:
+                delta = torch.empty((4, B, L, D), device=dev, dtype=torch.float32)
+            else:
+                delta = None if fuse_dt else _dtproj_fwd(proj, wdt, B, L, D, R, C, act_bias=bias if act else None)
             P = MsScanParams()
             _ss2d_params(P, xc, proj, delta, A, Dv, bias, y4, x_state, H, W, N, R, a_is_log=True)
-            if act:
+            if act and not fuse_dt_train:
                 P.delta_softplus |= 512             # MS_SCAN_DELTA_ACTIVATED
             if fuse_dt:
                 P.delta_softplus |= 128             # MS_SCAN_DT_FUSED
                 P.dt_x, P.dt_w, P.dt_rank, P.x = proj.data_ptr(), wdt.data_ptr(), R, None
+            if fuse_dt_train:
+                P.delta_softplus |= 128 | 1024      # MS_SCAN_DT_FUSED | MS_SCAN_DELTA_OUT
+                P.dt_x, P.dt_w, P.dt_rank = proj.data_ptr(), wdt.data_ptr(), R
             rc = TIMER.launch("scan_fwd", algorithmic_bytes(B, 4 * D, L, N, 4, False), dev,
                               lambda: lib.ms_selective_scan_fwd(ctypes.byref(P), stream), B * 4 * D * L * N)
             _lib.check(rc, "ms_selective_scan_fwd[ss2d]")

@@ -833,6 +833,19 @@ def test_scan_fused_dt_projection_forward(cfg):
     sc = float(np.abs(outs[0][0]).max())
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=0, atol=2e-5 * sc)       # fp32 sum order of the R products only
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=0, atol=2e-5 * float(np.abs(outs[0][1]).max()))
+    # MS_SCAN_DELTA_OUT (the training form): same outputs, and `delta` receives delta' = softplus(dts . Wdt + bias) at every position
+    dout = torch.full((4, bs, L, D), float("nan"), device=d)
+    y4 = torch.full((4, bs, L, D), float("nan"), device=d)
+    xs = torch.full((bs, lib.ms_scan_n_chunks(L), N, 4 * D), float("nan"), device=d)
+    P = MsScanParams()
+    _ss2d_params(P, xc, proj, dout, A, Dp, bias, y4, xs, H, W, N, R, a_is_log=True)
+    P.delta_softplus |= 128 | 1024
+    P.dt_x, P.dt_w, P.dt_rank = proj.data_ptr(), wdt.data_ptr(), R
+    _lib.check(lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(d)), "scan")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y4.cpu().numpy(), outs[1][0])
+    want = torch.nn.functional.softplus(delta.double() + bias.double().view(4, 1, 1, D)).float()
+    np.testing.assert_allclose(dout.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
 
 
 def test_batchnorm_statistics_with_a_large_mean():
