@@ -328,6 +328,34 @@ int ms_rms_gate_bwd(const float *y, int64_t dir_stride, int ndir, const void *z,
 int ms_ssd_chunk_carry(const float *in, const float *decay, float *out, const float *fwd_out, float *ddecay, int batch, int chunks,
                        int groups, int dstate, int heads_per_group, int headdim, int reverse, void *stream);
 
+/* The chunked SSD evaluation itself on the matrix cores (csrc/ssd_chunk.hip; exact-fp32 MFMA, 64-position chunks): what
+ * `mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D, z=None, dt_bias, dt_softplus)` computes at CNN_Mamba.py:523-537 /
+ * CrossMamba_fusion_2b2.py:327,590.  Operands fp32 contiguous: x, y (batch, L, heads, 64); dt (batch, L, heads) raw; A, dt_bias (heads);
+ * B, C (batch, L, dstate) (one group); dstate % 64 == 0; D (heads) or (heads, 64) or NULL.  Workspaces the caller owns
+ * (nc = ceil(L / 64)): dtv, cum (batch, nc, heads, 64); decay (batch, nc, heads); CB (batch, nc, 64, 64); S (batch, nc, dstate, heads * 64).
+ *   ms_ssd_chunk_fwd      : dtv = softplus?(dt + bias), cum = in-chunk prefix sums of dtv * A, decay = exp(cum_last), CB = C B^T per chunk,
+ *                           S = every chunk's state contribution, y = the inside-the-chunk output
+ *   (caller)              : S_in = ms_ssd_chunk_carry(S, decay)
+ *   ms_ssd_chunk_fwd_off  : y += diag(exp(cum)) C S_in + D x */
+int ms_ssd_chunk_fwd(const float *x, const float *dt, const float *A, const float *B, const float *C, const float *dt_bias, int dt_softplus,
+                     float *dtv, float *cum, float *decay, float *CB, float *S, float *y, int batch, int L, int heads, int headdim,
+                     int dstate, void *stream);
+int ms_ssd_chunk_fwd_off(const float *x, const float *C, const float *S_in, const float *cum, const float *D, int d_has_hdim, float *y,
+                         int batch, int L, int heads, int headdim, int dstate, void *stream);
+
+/* Backward of the chunked SSD evaluation (csrc/ssd_chunk.hip).  With the forward's workspaces (dtv, cum, decay, CB, S_in):
+ *   ms_ssd_chunk_bwd_off : dS_in (batch, nc, dstate, heads * 64) = gradient of the entering states, dcum_off (batch, nc, heads, 64)
+ *   (caller)             : dS, ddecay = ms_ssd_chunk_carry(dS_in, decay, reverse = 1, fwd_out = S_in)     (ddecay zero-filled first)
+ *   ms_ssd_chunk_bwd     : dx (batch, L, heads, 64), ddt (batch, L, heads) w.r.t. the RAW dt, dB, dC (batch, L, dstate) WRITTEN;
+ *                          dA, dbias (heads), dD (heads) | (heads, 64), dCB (batch, nc, 64, 64) ACCUMULATED (zero them first; dCB is a
+ *                          workspace: the heads' sum of the masked score gradient).  dbias / dD / D may be NULL. */
+int ms_ssd_chunk_bwd_off(const float *dy, const float *C, const float *S_in, const float *cum, float *dS_in, float *dcum_off, int batch, int L,
+                         int heads, int headdim, int dstate, void *stream);
+int ms_ssd_chunk_bwd(const float *x, const float *dy, const float *B, const float *C, const float *CB, const float *S_in, const float *dS,
+                     const float *dtv, const float *cum, const float *decay, const float *ddecay, const float *A, const float *D,
+                     int d_has_hdim, int dt_softplus, const float *dcum_off, float *dx, float *ddt, float *dA, float *dbias, float *dD,
+                     float *dCB, float *dB, float *dC, int batch, int L, int heads, int headdim, int dstate, void *stream);
+
 /* ---- the dense projections of SS2D on the matrix cores (in_proj, x_proj, out_proj: MedMamba.py:284,326,397,469,480) --------
  * C[i][j] (+)= sum_k Aop[i][k] * Bop[j][k]   for i < M, j < N, k < K; bf16 MFMA, fp32 accumulation
  *   Aop[i][k] = a_trans ? A[k*lda + i] : A[i*lda + k]      A, B: bf16 or fp32 in memory (`*_is_f32`; fp32 operands are rounded to

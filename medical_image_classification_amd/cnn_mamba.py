@@ -171,6 +171,107 @@ class _SSDChunked(torch.autograd.Function):
         return tuple(next(grads) if (t is not None and t.requires_grad) else None for t in ins) + (None,)
 
 
+# ---- the chunked form on this package's MFMA kernels (csrc/ssd_chunk.hip) ------------------------------------------------------
+SSD_CHUNK_KERNELS = os.environ.get("MEDSCAN_SSD_CHUNK_KERNELS", "1") == "1"
+
+
+def _ssd_kernels_ok(x, B):
+    """shapes the fused chunk kernels take: headdim 64, one B/C group, a state dimension that is a multiple of 64"""
+    return SSD_CHUNK_KERNELS and x.is_cuda and x.shape[-1] == 64 and B.shape[2] == 1 and B.shape[3] % 64 == 0
+
+
+def _ssd_chunk_forward(x, dt, A, B, C, D, dt_bias, dt_softplus):
+    """ms_ssd_chunk_fwd -> ms_ssd_chunk_carry -> ms_ssd_chunk_fwd_off.  Returns y and the workspaces the backward re-uses."""
+    b, l, h, p = x.shape
+    n = B.shape[3]
+    nc = (l + 63) // 64
+    dev = x.device
+    f32 = lambda t: t.detach().float().contiguous()
+    x, dt, A, B, C = f32(x), f32(dt), f32(A), f32(B).view(b, l, n), f32(C).view(b, l, n)
+    D = f32(D) if D is not None else None
+    bias = f32(dt_bias) if dt_bias is not None else None
+    dtv = torch.empty((b, nc, h, 64), device=dev, dtype=torch.float32)
+    cum = torch.empty_like(dtv)
+    decay = torch.empty((b, nc, h), device=dev, dtype=torch.float32)
+    CB = torch.empty((b, nc, 64, 64), device=dev, dtype=torch.float32)
+    S = torch.empty((b, nc, n, h * p), device=dev, dtype=torch.float32)
+    y = torch.empty((b, l, h, p), device=dev, dtype=torch.float32)
+    lib, st = _lib.lib(), _lib.current_stream_ptr(dev)
+    with _lib.on_device(dev):
+        _lib.check(lib.ms_ssd_chunk_fwd(x.data_ptr(), dt.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, int(bool(dt_softplus)), dtv.data_ptr(), cum.data_ptr(),
+                                        decay.data_ptr(), CB.data_ptr(), S.data_ptr(), y.data_ptr(), b, l, h, p, n, st), "ms_ssd_chunk_fwd")
+        S_in = torch.empty_like(S)
+        _lib.check(lib.ms_ssd_chunk_carry(S.data_ptr(), decay.data_ptr(), S_in.data_ptr(), None, None, b, nc, 1, n, h, p, 0, st),
+                   "ms_ssd_chunk_carry")
+        _lib.check(lib.ms_ssd_chunk_fwd_off(x.data_ptr(), C.data_ptr(), S_in.data_ptr(), cum.data_ptr(),
+                                            D.data_ptr() if D is not None else None, int(D is not None and D.dim() == 2), y.data_ptr(),
+                                            b, l, h, p, n, st), "ms_ssd_chunk_fwd_off")
+    return y, (x, dt, A, B, C, D, bias, dtv, cum, decay, CB, S_in)
+
+
+class _SSDChunkKernels(torch.autograd.Function):
+    """mamba_chunk_scan_combined on csrc/ssd_chunk.hip: forward and backward on the exact-fp32 matrix instruction, no torch.matmul, none
+    of the (chunks x heads x 64 x 64) mask tensors.  The entering states S_in ((l / 64) x n x h*p floats per sample -- 1.6 GB for one
+    stage-0 scan of VFEFM at batch 32) are kept for the backward up to MEDSCAN_SSD_KEEP_STATE_GB and recomputed above it."""
+
+    @staticmethod
+    def forward(ctx, x, dt, A, B, C, D, dt_bias, dt_softplus):
+        y, ws = _ssd_chunk_forward(x, dt, A, B, C, D, dt_bias, dt_softplus)
+        xf, dtf, Af, Bf, Cf, Df, bias, dtv, cum, decay, CB, S_in = ws
+        keep = S_in.numel() * 4 <= SSD_KEEP_STATE_BYTES
+        ctx.save_for_backward(xf, dtf, Af, Bf, Cf, Df, bias, dtv, cum, decay, CB, S_in if keep else None)
+        ctx.dt_softplus = bool(dt_softplus)
+        ctx.meta = (x.dtype, dt.dtype, A.dtype, B.dtype, C.dtype, D.dtype if D is not None else None, dt_bias.dtype if dt_bias is not None else None,
+                    tuple(B.shape), tuple(D.shape) if D is not None else None, tuple(dt_bias.shape) if dt_bias is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, dt, A, B, C, D, bias, dtv, cum, decay, CB, S_in = ctx.saved_tensors
+        b, l, h, p = x.shape
+        n = B.shape[2]
+        nc = (l + 63) // 64
+        dev = x.device
+        dy = dy.float().contiguous()
+        lib, st = _lib.lib(), _lib.current_stream_ptr(dev)
+        with _lib.on_device(dev):
+            S = torch.empty((b, nc, n, h * p), device=dev, dtype=torch.float32)
+            if S_in is None:               # recompute the entering states (states only: no Y)
+                _lib.check(lib.ms_ssd_chunk_fwd(x.data_ptr(), dt.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr(),
+                                                bias.data_ptr() if bias is not None else None, int(ctx.dt_softplus), dtv.data_ptr(),
+                                                cum.data_ptr(), decay.data_ptr(), CB.data_ptr(), S.data_ptr(), None, b, l, h, p, n, st),
+                           "ms_ssd_chunk_fwd[states]")
+                S_in = torch.empty_like(S)
+                _lib.check(lib.ms_ssd_chunk_carry(S.data_ptr(), decay.data_ptr(), S_in.data_ptr(), None, None, b, nc, 1, n, h, p, 0, st),
+                           "ms_ssd_chunk_carry")
+            dS_in, dcum = S, torch.empty((b, nc, h, 64), device=dev, dtype=torch.float32)          # (S is free again: dS_in takes its place)
+            _lib.check(lib.ms_ssd_chunk_bwd_off(dy.data_ptr(), C.data_ptr(), S_in.data_ptr(), cum.data_ptr(), dS_in.data_ptr(), dcum.data_ptr(),
+                                                b, l, h, p, n, st), "ms_ssd_chunk_bwd_off")
+            dS = torch.empty_like(S_in)
+            nd = D.numel() if D is not None else 0
+            small = torch.zeros(b * nc * h + 2 * h + nd, device=dev, dtype=torch.float32)          # ddecay | dA | dbias | dD: one fill
+            ddecay, dA, dbias = small[:b * nc * h], small[b * nc * h:b * nc * h + h], small[b * nc * h + h:b * nc * h + 2 * h]
+            dD = small[b * nc * h + 2 * h:].view(D.shape) if D is not None else None
+            dCB = torch.zeros((b, nc, 64, 64), device=dev, dtype=torch.float32)
+            if nc > 1:
+                dS_in[:, 0].zero_()        # never written by the off kernel (chunk 0 has no entering state) and never read by the carry: keep it finite
+            _lib.check(lib.ms_ssd_chunk_carry(dS_in.data_ptr(), decay.data_ptr(), dS.data_ptr(), S_in.data_ptr(), ddecay.data_ptr(),
+                                              b, nc, 1, n, h, p, 1, st), "ms_ssd_chunk_carry[reverse]")
+            dx = torch.empty_like(x)
+            ddt = torch.empty_like(dt)
+            dB, dC = torch.empty_like(B), torch.empty_like(C)
+            _lib.check(lib.ms_ssd_chunk_bwd(x.data_ptr(), dy.data_ptr(), B.data_ptr(), C.data_ptr(), CB.data_ptr(), S_in.data_ptr(), dS.data_ptr(),
+                                            dtv.data_ptr(), cum.data_ptr(), decay.data_ptr(), ddecay.data_ptr(), A.data_ptr(),
+                                            D.data_ptr() if D is not None else None, int(D is not None and D.dim() == 2), int(ctx.dt_softplus),
+                                            dcum.data_ptr(), dx.data_ptr(), ddt.data_ptr(), dA.data_ptr(),
+                                            dbias.data_ptr() if bias is not None else None, dD.data_ptr() if dD is not None else None,
+                                            dCB.data_ptr(), dB.data_ptr(), dC.data_ptr(), b, l, h, p, n, st), "ms_ssd_chunk_bwd")
+        xd, dtd, Ad, Bd, Cd, Dd, bd, Bshape, Dshape, bshape = ctx.meta
+        return (dx.to(xd), ddt.to(dtd), dA.to(Ad), dB.view(Bshape).to(Bd), dC.view(Bshape).to(Cd),
+                dD.view(Dshape).to(Dd) if D is not None else None, dbias.view(bshape).to(bd) if bias is not None else None, None)
+
+
 def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt_bias=None, initial_states=None,
                               seq_idx=None, cu_seqlens=None, dt_softplus=False, dt_limit=(0.0, float("inf")),
                               return_final_states=False):

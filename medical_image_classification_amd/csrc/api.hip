@@ -69,11 +69,47 @@ int bn_bwd_dispatch(const void *x, int x_bf16, int64_t xps, const void *dy, int 
                     float *scratch, int64_t npix, int C, hipStream_t s);
 int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
                        int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream);
+int ssd_chunk_fwd_dispatch(const float *x, const float *dt, const float *A, const float *B, const float *C, const float *dt_bias,
+                           int softplus, float *dtv, float *cum, float *decay, float *CB, float *S, float *y, int batch, int L, int H,
+                           int P, int N, hipStream_t s);
+int ssd_chunk_fwd_off_dispatch(const float *x, const float *C, const float *Sin, const float *cum, const float *D, int d_has_hdim, float *y,
+                               int batch, int L, int H, int P, int N, hipStream_t s);
+int ssd_chunk_bwd_off_dispatch(const float *dy, const float *C, const float *Sin, const float *cum, float *dSin, float *dcum, int batch, int L,
+                               int H, int P, int N, hipStream_t s);
+int ssd_chunk_bwd_dispatch(const float *x, const float *dy, const float *B, const float *C, const float *CB, const float *Sin, const float *dS,
+                           const float *dtv, const float *cum, const float *decay, const float *ddecay, const float *A, const float *D,
+                           int d_has_hdim, int softplus, const float *dcum_off, float *dx, float *ddt, float *dA, float *dbias, float *dD,
+                           float *dCB, float *dB, float *dC, int batch, int L, int H, int P, int N, hipStream_t s);
 int gemm_f32_dispatch(const float *A, int a_trans, int64_t lda, const float *B, int b_trans, int64_t ldb, float *C, int c_mode, int64_t ldc,
                       int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream);
 }  // namespace ms
 
 extern "C" {
+
+int ms_ssd_chunk_fwd(const float *x, const float *dt, const float *A, const float *B, const float *C, const float *dt_bias, int dt_softplus,
+                     float *dtv, float *cum, float *decay, float *CB, float *S, float *y, int batch, int L, int heads, int headdim,
+                     int dstate, void *stream) {
+    return ms::ssd_chunk_fwd_dispatch(x, dt, A, B, C, dt_bias, dt_softplus, dtv, cum, decay, CB, S, y, batch, L, heads, headdim, dstate,
+                                      (hipStream_t)stream);
+}
+
+int ms_ssd_chunk_fwd_off(const float *x, const float *C, const float *S_in, const float *cum, const float *D, int d_has_hdim, float *y,
+                         int batch, int L, int heads, int headdim, int dstate, void *stream) {
+    return ms::ssd_chunk_fwd_off_dispatch(x, C, S_in, cum, D, d_has_hdim, y, batch, L, heads, headdim, dstate, (hipStream_t)stream);
+}
+
+int ms_ssd_chunk_bwd_off(const float *dy, const float *C, const float *S_in, const float *cum, float *dS_in, float *dcum_off, int batch, int L,
+                         int heads, int headdim, int dstate, void *stream) {
+    return ms::ssd_chunk_bwd_off_dispatch(dy, C, S_in, cum, dS_in, dcum_off, batch, L, heads, headdim, dstate, (hipStream_t)stream);
+}
+
+int ms_ssd_chunk_bwd(const float *x, const float *dy, const float *B, const float *C, const float *CB, const float *S_in, const float *dS,
+                     const float *dtv, const float *cum, const float *decay, const float *ddecay, const float *A, const float *D,
+                     int d_has_hdim, int dt_softplus, const float *dcum_off, float *dx, float *ddt, float *dA, float *dbias, float *dD,
+                     float *dCB, float *dB, float *dC, int batch, int L, int heads, int headdim, int dstate, void *stream) {
+    return ms::ssd_chunk_bwd_dispatch(x, dy, B, C, CB, S_in, dS, dtv, cum, decay, ddecay, A, D, d_has_hdim, dt_softplus, dcum_off, dx, ddt, dA,
+                                      dbias, dD, dCB, dB, dC, batch, L, heads, headdim, dstate, (hipStream_t)stream);
+}
 
 int ms_gemm_f32(const float *A, int a_trans, int64_t lda, const float *B, int b_trans, int64_t ldb, float *C, int c_mode, int64_t ldc,
                 int M, int N, int K, int k_splits, const float *bias, int relu, void *stream) {
