@@ -42,7 +42,9 @@ _STATE_SLICE = 16      # states per kernel call (the backward kernels are built 
 # Triton): one launch set for ALL states instead of one scan launch per 16 states.  Used when the state is wide enough
 # for the GEMMs to win: measured at 512 states (VFEFM, bs 32) 2.34 s -> 1.36 s per step; at 64 states (CNN_Mamba.VSSM,
 # bs 32) the scan kernels win, 46 vs 74 ms.  0 = always the scan kernels.
-SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "128"))
+# Round 3: with the chunked form on this package's own MFMA kernels (csrc/ssd_chunk.hip, _SSDChunkKernels below) it wins from 64 states
+# on as well (CNN_Mamba.VSSM bs 32: see DESIGN.md 9): the default threshold is 64.
+SSD_CHUNKED_MIN_STATE = int(os.environ.get("MEDSCAN_SSD_CHUNKED_MIN_STATE", "64"))
 # Scans whose chunk-state tensor is at most this large keep their intermediates for backward (plain autograd); larger ones
 # keep only their operands and recompute (_SSDChunked).  Measured on VFEFM bs 32 (ms/step, peak HBM): 0 GB 883 / 52 GiB,
 # 0.5 GB 861 / 58, 1 GB 816 / 97, 2 GB 798 / 141, everything kept 1056* / 250 (*before the carry kernel).  288 GB of HBM3E
@@ -288,7 +290,10 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=256, D=None, z=None, dt
     g, n = B.shape[2], B.shape[3]
     if h % g != 0:
         raise RuntimeError("mamba_chunk_scan_combined: nheads must be a multiple of ngroups")
-    if 0 < SSD_CHUNKED_MIN_STATE <= n:
+    if 0 < SSD_CHUNKED_MIN_STATE <= n and _ssd_kernels_ok(x, B):
+        with torch.autocast(device_type="cuda", enabled=False):          # the chunked form on csrc/ssd_chunk.hip (exact-fp32 MFMA)
+            return _SSDChunkKernels.apply(x, dt, A, B, C, D, dt_bias, dt_softplus).to(x.dtype)
+    if 0 < max(SSD_CHUNKED_MIN_STATE, 128) <= n:       # shapes the kernels do not take: the torch formulation (library GEMMs), wide states only
         with torch.autocast(device_type="cuda", enabled=False):
             # the chunk-state tensors ((l / chunk) x n x h*p floats per sample; autograd would keep ~5 of them) decide whether
             # the scan keeps its intermediates or only its operands
@@ -526,7 +531,10 @@ def ssd_scan_merge(mod, xc):
     B, H, W, conv_dim = xc.shape
     L, K = H * W, 4
     GN = mod.ngroups * mod.d_state
-    chunked = 0 < SSD_CHUNKED_MIN_STATE <= K * mod.d_state          # wide state: gathered sequences + chunked GEMMs
+    # gathered sequences + the chunked evaluation: on the MFMA kernels when they take the shape (headdim 64, one group, 4 N % 64 == 0),
+    # else (torch formulation) only for wide states
+    kern_ok = SSD_CHUNK_KERNELS and mod.headdim == 64 and mod.ngroups == 1 and (K * mod.d_state) % 64 == 0
+    chunked = 0 < SSD_CHUNKED_MIN_STATE <= K * mod.d_state and (kern_ok or K * mod.d_state >= 128)
     if SSD_PIXEL_ORDER and mod.ngroups == 1 and H * W < (1 << 22) and not chunked:
         # native path: the scan kernels take the four pixel orders themselves, one launch per direction's B/C slice
         from .ss2d_fused import ssd_scan_merge_pixel

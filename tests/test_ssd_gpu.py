@@ -540,3 +540,72 @@ def test_vfefm_224_batch4_matches_cpu_oracle():
         assert checked > 60
     finally:
         ssd_oracle.install_ssd(torch.nn.Module())          # back to the float64 loop for the other tests of this process
+
+
+@pytest.mark.parametrize("cfg", [(2, 200, 4, 64, False), (1, 64, 2, 128, True), (2, 49, 8, 512, False), (1, 1, 3, 64, False), (2, 65, 2, 64, True),
+                                 (1, 127, 1, 192, False)])
+@pytest.mark.parametrize("recompute", [False, True])
+def test_ssd_chunk_mfma_kernels_vs_restatement(cfg, recompute, monkeypatch):
+    """csrc/ssd_chunk.hip (the chunked SSD evaluation on the exact-fp32 matrix instruction: forward AND backward, no torch.matmul) against
+    the sequential float64 restatement: output and all seven gradients at 1e-3 / 2e-3 (measured ~1e-6) -- chunk-ragged lengths (1, 49,
+    65, 127, 200), 64 / 128 / 192 / 512 states, D per head and per (head, channel); `recompute`: the entering states are not kept for the
+    backward (MEDSCAN_SSD_KEEP_STATE_GB = 0) but recomputed.  And no library GEMM runs: aten mm / bmm / matmul are never dispatched."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from medical_image_classification_amd import cnn_mamba as cm
+    b, l, h, n, hdim_D = cfg
+    p = 64
+    monkeypatch.setattr(cm, "SSD_CHUNKED_MIN_STATE", 64)
+    if recompute:
+        monkeypatch.setattr(cm, "SSD_KEEP_STATE_BYTES", 0)
+    gen = torch.Generator().manual_seed(l + n)
+    mk = lambda *s: torch.randn(*s, generator=gen)
+    x, dt, B, C = mk(b, l, h, p), mk(b, l, h) - 1.0, mk(b, l, 1, n) * 0.3, mk(b, l, 1, n) * 0.3
+    A = -torch.rand(h, generator=gen) * 4 - 0.2
+    D = mk(h, p) if hdim_D else mk(h)
+    bias = mk(h) * 0.5
+    gy = mk(b, l, h, p)
+    cpu = [t.clone().requires_grad_() for t in (x, dt, A, B, C, D, bias)]
+    gpu = [t.to(dev()).requires_grad_() for t in (x, dt, A, B, C, D, bias)]
+    yr = ssd_oracle.ssd_scan_ref(cpu[0], cpu[1], cpu[2], cpu[3], cpu[4], D=cpu[5], dt_bias=cpu[6], dt_softplus=True)
+    yr.backward(gy)
+
+    class Audit(TorchDispatchMode):
+        def __init__(self):
+            super().__init__(); self.seen = []
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            nm = func.__name__.split(".")[0]
+            if nm in ("mm", "addmm", "bmm", "baddbmm", "matmul", "einsum"):
+                self.seen.append(nm)
+            return func(*args, **(kwargs or {}))
+
+    with Audit() as a:
+        yd = cm.mamba_chunk_scan_combined(gpu[0], gpu[1], gpu[2], gpu[3], gpu[4], chunk_size=256, D=gpu[5], z=None, dt_bias=gpu[6], dt_softplus=True)
+        yd.backward(gy.to(dev()))
+    assert not a.seen, a.seen
+    close(yd, yr, 1e-3, "y")
+    for name, g_, r_ in zip(("dx", "ddt", "dA", "dB", "dC", "dD", "dbias"), gpu, cpu):
+        close(g_.grad, r_.grad, 2e-3, name)
+
+
+def test_ssd_chunk_mfma_kernels_plain_dt_and_error_returns():
+    """dt_softplus = False, no bias, no D through the kernels; shapes they do not take fall back (n = 40) or are refused at the C ABI."""
+    from medical_image_classification_amd import _lib, cnn_mamba as cm
+    gen = torch.Generator().manual_seed(9)
+    x, dt = torch.randn(1, 70, 2, 64, generator=gen), torch.rand(1, 70, 2, generator=gen) * 0.5
+    A, B, C = -torch.ones(2), torch.randn(1, 70, 1, 64, generator=gen) * 0.3, torch.randn(1, 70, 1, 64, generator=gen) * 0.3
+    cpu = [t.clone().requires_grad_() for t in (x, dt, A, B, C)]
+    gpu = [t.to(dev()).requires_grad_() for t in (x, dt, A, B, C)]
+    yr = ssd_oracle.ssd_scan_ref(*cpu)
+    yd = cm.mamba_chunk_scan_combined(*gpu, chunk_size=64)
+    g = torch.randn(1, 70, 2, 64, generator=gen)
+    yr.backward(g); yd.backward(g.to(dev()))
+    close(yd, yr, 1e-3, "y")
+    for name, g_, r_ in zip(("dx", "ddt", "dA", "dB", "dC"), gpu, cpu):
+        close(g_.grad, r_.grad, 2e-3, name)
+    assert not cm._ssd_kernels_ok(torch.zeros(1, 4, 2, 64, device=dev()), torch.zeros(1, 4, 1, 40, device=dev()))      # 40 states: not a tile multiple
+    lib, st = _lib.lib(), _lib.current_stream_ptr(dev())
+    z = torch.zeros(64 * 64 * 4, device=dev()); q = z.data_ptr()
+    assert lib.ms_ssd_chunk_fwd(None, q, q, q, q, None, 1, q, q, q, q, q, q, 1, 64, 1, 64, 64, st) == -1
+    assert lib.ms_ssd_chunk_fwd(q, q, q, q, q, None, 1, q, q, q, q, q, q, 1, 64, 1, 32, 64, st) == -2          # headdim 32
+    assert lib.ms_ssd_chunk_fwd(q, q, q, q, q, None, 1, q, q, q, q, q, q, 1, 64, 1, 64, 40, st) == -2          # 40 states
+    assert lib.ms_ssd_chunk_bwd_off(q, q, q, q, None, q, 1, 64, 1, 64, 64, st) == -1
