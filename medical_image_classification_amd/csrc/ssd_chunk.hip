@@ -63,17 +63,33 @@ __device__ __forceinline__ void zero4(f32x4 (&a)[4]) {
     for (int i = 0; i < 4; ++i) a[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// Stage a [64 rows][64 columns] fp32 tile, rows `ld` floats apart in memory, into LDS as s[row][col] (pitch kTPc): thread -> 4 pieces
-// of 16 bytes (row = id / 16, piece = id % 16); rows >= nrows read as zero.  `rscale` (LDS, 64 floats): row r is multiplied by it.
-__device__ __forceinline__ void stage_tile(float *s, const float *g, int64_t ld, int nrows, int tid, const float *rscale = nullptr) {
+// A [64 rows][64 columns] fp32 tile, rows `ld` floats apart in memory, staged into LDS as s[row][col] (pitch kTPc) in two phases so that the
+// NEXT tile's loads are in flight while the current one is multiplied: fetch() -> registers (thread -> 4 pieces of 16 bytes, row =
+// id / 16, piece = id % 16; rows >= nrows read as zero), put() -> LDS, with an optional per-row scale `rscale` (LDS, 64 floats).
+struct TileRegs {
+    float4 v[4];
+    __device__ __forceinline__ void fetch(const float *g, int64_t ld, int nrows, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i, row = id >> 4, pc = id & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nrows) v = ld4c(g + (int64_t)row * ld + pc * 4);
-        if (rscale) { const float sc = rscale[row]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-        st4c(s + row * kTPc + pc * 4, v);
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i, row = id >> 4, pc = id & 15;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nrows) v[i] = ld4c(g + (int64_t)row * ld + pc * 4);
+        }
     }
+    __device__ __forceinline__ void put(float *s, int tid, const float *rscale = nullptr) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i, row = id >> 4, pc = id & 15;
+            float4 t = v[i];
+            if (rscale) { const float sc = rscale[row]; t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc; }
+            st4c(s + row * kTPc + pc * 4, t);
+        }
+    }
+};
+__device__ __forceinline__ void stage_tile(float *s, const float *g, int64_t ld, int nrows, int tid, const float *rscale = nullptr) {
+    TileRegs r;
+    r.fetch(g, ld, nrows, tid);
+    r.put(s, tid, rscale);
 }
 
 // ---- prep: dt' = softplus(dt + bias) (or dt + bias), cum = prefix sums of dt' A inside each chunk, decay = exp(cum_last) -----------
@@ -115,11 +131,13 @@ ssd_cb_kernel(const float *__restrict__ Bm, const float *__restrict__ Cm, float 
     const float *Bg = Bm + ((int64_t)b * L + l0) * N, *Cg = Cm + ((int64_t)b * L + l0) * N;
     f32x4 acc[4];
     zero4(acc);
+    TileRegs rb, rc;
+    rb.fetch(Bg, N, nrows, tid); rc.fetch(Cg, N, nrows, tid);
     for (int n0 = 0; n0 < N; n0 += kQc) {
         __syncthreads();
-        stage_tile(sB, Bg + n0, N, nrows, tid);
-        stage_tile(sC, Cg + n0, N, nrows, tid);
+        rb.put(sB, tid); rc.put(sC, tid);
         __syncthreads();
+        if (n0 + kQc < N) { rb.fetch(Bg + n0 + kQc, N, nrows, tid); rc.fetch(Cg + n0 + kQc, N, nrows, tid); }
         mma_16x64<false, false, false>(acc, sC, 16 * w, sB, nullptr, lane);        // rows i: C, columns j: B, k: states
     }
     const int fr = lane & 15, fq = lane >> 4;
@@ -161,10 +179,13 @@ ssd_intra_kernel(const float *__restrict__ x, const float *__restrict__ Bm, cons
     const int fr = lane & 15, fq = lane >> 4;
     const float *Bg = Bm + ((int64_t)b * L + l0) * N;
     float *Sg = S + (((int64_t)b * nc + c) * N) * ((int64_t)H * kQc) + (int64_t)hh * kQc;
+    TileRegs rb;
+    rb.fetch(Bg, N, nrows, tid);
     for (int n0 = 0; n0 < N; n0 += kQc) {
         __syncthreads();                                        // the previous tile's fragments are read (first trip: sXt / sDec written)
-        stage_tile(sB, Bg + n0, N, nrows, tid);
+        rb.put(sB, tid);
         __syncthreads();
+        if (n0 + kQc < N) rb.fetch(Bg + n0 + kQc, N, nrows, tid);
         f32x4 acc[4];
         zero4(acc);
         mma_16x64<true, false, true>(acc, sB, 16 * w, sXt, sDec, lane);       // rows nn: B^T (scaled by dec_j along k = j), columns p: X'^T
@@ -217,11 +238,14 @@ ssd_off_kernel(const float *__restrict__ x, const float *__restrict__ Cm, const 
     if (c > 0) {                                                                    // chunk 0 starts from the zero state
         const float *Cg = Cm + ((int64_t)b * L + l0) * N;
         const float *Sg = Sin + (((int64_t)b * nc + c) * N) * ((int64_t)H * kQc) + (int64_t)hh * kQc;
+        const int64_t HS = (int64_t)H * kQc;
+        TileRegs rc, rs;
+        rc.fetch(Cg, N, nrows, tid); rs.fetch(Sg, HS, kQc, tid);
         for (int n0 = 0; n0 < N; n0 += kQc) {
             __syncthreads();
-            stage_tile(sC, Cg + n0, N, nrows, tid);
-            stage_tile(sS, Sg + (int64_t)n0 * ((int64_t)H * kQc), (int64_t)H * kQc, kQc, tid);
+            rc.put(sC, tid); rs.put(sS, tid);
             __syncthreads();
+            if (n0 + kQc < N) { rc.fetch(Cg + n0 + kQc, N, nrows, tid); rs.fetch(Sg + (int64_t)(n0 + kQc) * HS, HS, kQc, tid); }
             mma_16x64<false, true, false>(acc, sC, 16 * w, sS, nullptr, lane);        // rows i: C, columns p: S_in^T (stored [nn][p]), k: nn
         }
     }
@@ -279,11 +303,13 @@ ssd_bwd_off_kernel(const float *__restrict__ dy, const float *__restrict__ Cm, c
     float *dSg = dSin + (((int64_t)b * nc + c) * N) * HS + (int64_t)hh * kQc;
     f32x4 wacc[4];
     zero4(wacc);
+    TileRegs rc, rs;
+    rc.fetch(Cg, N, nrows, tid); rs.fetch(Sg, HS, kQc, tid);
     for (int n0 = 0; n0 < N; n0 += kQc) {
         __syncthreads();
-        stage_tile(sC, Cg + n0, N, nrows, tid);
-        stage_tile(sS, Sg + (int64_t)n0 * HS, HS, kQc, tid);
+        rc.put(sC, tid); rs.put(sS, tid);
         __syncthreads();
+        if (n0 + kQc < N) { rc.fetch(Cg + n0 + kQc, N, nrows, tid); rs.fetch(Sg + (int64_t)(n0 + kQc) * HS, HS, kQc, tid); }
         mma_16x64<false, true, false>(wacc, sC, 16 * w, sS, nullptr, lane);             // W: rows i (C), columns p (S_in^T), k: nn
         f32x4 acc[4];
         zero4(acc);
@@ -337,11 +363,13 @@ ssd_bwd_main_kernel(const float *__restrict__ x, const float *__restrict__ dy, c
     {
         const float *Bg = Bm + ((int64_t)b * L + l0) * N;
         const float *dSg = dS + (((int64_t)b * nc + c) * N) * HS + (int64_t)hh * kQc;
+        TileRegs rb, rs;
+        rb.fetch(Bg, N, nrows, tid); rs.fetch(dSg, HS, kQc, tid);
         for (int n0 = 0; n0 < N; n0 += kQc) {
             __syncthreads();
-            stage_tile(sB, Bg + n0, N, nrows, tid);
-            stage_tile(sU, dSg + (int64_t)n0 * HS, HS, kQc, tid);
+            rb.put(sB, tid); rs.put(sU, tid);
             __syncthreads();
+            if (n0 + kQc < N) { rb.fetch(Bg + n0 + kQc, N, nrows, tid); rs.fetch(dSg + (int64_t)(n0 + kQc) * HS, HS, kQc, tid); }
             mma_16x64<false, true, false>(G, sB, 16 * w, sU, nullptr, lane);                // rows j (B), columns p (dS^T), k: nn
         }
     }
@@ -463,7 +491,10 @@ ssd_bwd_main_kernel(const float *__restrict__ x, const float *__restrict__ dy, c
     }
 }
 
-// ---- per (batch, chunk, 64-state tile): dB and dC, every head's contribution summed in registers ----------------------------------------
+// ---- per (batch, chunk, NTW 64-state tiles): dB and dC, every head's contribution summed in registers ------------------------------------
+// NTW tiles per workgroup: a head's dy / x tiles are staged once for NTW state tiles (with one tile per workgroup the kernel re-read dy
+// and x N / 64 times: 3.3 of its 6.4 GB per stage-0 scan of VFEFM); the S_in / dS tiles stream through registers one step ahead.
+template <int NTW>
 __global__ void __launch_bounds__(256)
 ssd_bwd_bc_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ Bm, const float *__restrict__ Cm,
                   const float *__restrict__ Sin, const float *__restrict__ dS, const float *__restrict__ dtv, const float *__restrict__ cum,
@@ -471,17 +502,21 @@ ssd_bwd_bc_kernel(const float *__restrict__ x, const float *__restrict__ dy, con
     __shared__ __attribute__((aligned(16))) float sA1[kTilec], sB1[kTilec], sA2[kTilec], sB2[kTilec];
     __shared__ __attribute__((aligned(16))) float sE[kQc], sSc[kQc];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ntl = N / kQc;
-    const int t0 = blockIdx.x % ntl, c = (blockIdx.x / ntl) % nc, b = blockIdx.x / (ntl * nc);
-    const int l0 = c * kQc, nrows = min(kQc, L - l0), n0 = t0 * kQc;
+    const int ngr = N / (kQc * NTW);
+    const int t0 = blockIdx.x % ngr, c = (blockIdx.x / ngr) % nc, b = blockIdx.x / (ngr * nc);
+    const int l0 = c * kQc, nrows = min(kQc, L - l0), n0 = t0 * kQc * NTW;
     const int64_t HS = (int64_t)H * kQc;
     const int fr = lane & 15, fq = lane >> 4;
-    f32x4 aC[4], aB[4];
-    zero4(aC); zero4(aB);
+    f32x4 aC[NTW][4], aB[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) { zero4(aC[t]); zero4(aB[t]); }
     const float *Sg = Sin + (((int64_t)b * nc + c) * N + n0) * HS, *dSg = dS + (((int64_t)b * nc + c) * N + n0) * HS;
+    TileRegs r1, r2;                                                                           // the next (S_in, dS) tiles
+    if (c > 0) r1.fetch(Sg, HS, kQc, tid);
+    r2.fetch(dSg, HS, kQc, tid);
     for (int hh = 0; hh < H; ++hh) {
         const int64_t bch = ((int64_t)b * nc + c) * H + hh;
-        __syncthreads();
+        __syncthreads();                                                                       // the previous head's tiles are read
         if (tid < kQc) {
             const float cv = cum[bch * kQc + tid];
             sE[tid] = exp_f(cv);
@@ -489,30 +524,44 @@ ssd_bwd_bc_kernel(const float *__restrict__ x, const float *__restrict__ dy, con
         }
         __syncthreads();
         const int64_t row0 = (((int64_t)b * L + l0) * H + hh) * kQc;
-        if (c > 0) {
-            stage_tile(sA1, dy + row0, HS, nrows, tid, sE);                                    // E_i dy[i][p]
-            stage_tile(sB1, Sg + (int64_t)hh * kQc, HS, kQc, tid);                            // S_in[nn][p]
-        }
+        if (c > 0) stage_tile(sA1, dy + row0, HS, nrows, tid, sE);                             // E_i dy[i][p]
         stage_tile(sA2, x + row0, HS, nrows, tid, sSc);                                        // dec_j X'[j][p]
-        stage_tile(sB2, dSg + (int64_t)hh * kQc, HS, kQc, tid);                                // dS[nn][p]
-        __syncthreads();
-        if (c > 0) mma_16x64<false, false, false>(aC, sA1, 16 * w, sB1, nullptr, lane);        // rows i, columns nn, k: p
-        mma_16x64<false, false, false>(aB, sA2, 16 * w, sB2, nullptr, lane);                   // rows j, columns nn, k: p
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t > 0) __syncthreads();                                                        // the previous state tiles are read
+            if (c > 0) r1.put(sB1, tid);                                                       // S_in[nn][p]
+            r2.put(sB2, tid);                                                                  // dS[nn][p]
+            __syncthreads();
+            {       // the next pair of state tiles: (hh, t + 1), or (hh + 1, 0)
+                const int tn = t + 1 < NTW ? t + 1 : 0, hn = t + 1 < NTW ? hh : hh + 1;
+                if (hn < H) {
+                    const int64_t off = (int64_t)tn * kQc * HS + (int64_t)hn * kQc;
+                    if (c > 0) r1.fetch(Sg + off, HS, kQc, tid);
+                    r2.fetch(dSg + off, HS, kQc, tid);
+                }
+            }
+            if (c > 0) mma_16x64<false, false, false>(aC[t], sA1, 16 * w, sB1, nullptr, lane);  // rows i, columns nn, k: p
+            mma_16x64<false, false, false>(aB[t], sA2, 16 * w, sB2, nullptr, lane);             // rows j, columns nn, k: p
+        }
     }
     __syncthreads();
     stage_tile(sA1, dCB + ((int64_t)b * nc + c) * kQc * kQc, kQc, kQc, tid);                   // dCB[i][j]
-    stage_tile(sB1, Bm + ((int64_t)b * L + l0) * N + n0, N, nrows, tid);                       // B[j][nn]
-    stage_tile(sA2, Cm + ((int64_t)b * L + l0) * N + n0, N, nrows, tid);                       // C[i][nn]
-    __syncthreads();
-    mma_16x64<false, true, false>(aC, sA1, 16 * w, sB1, nullptr, lane);                        // dC += dCB B:    rows i, columns nn (B^T of [j][nn]), k: j
-    mma_16x64<true, true, false>(aB, sA1, 16 * w, sA2, nullptr, lane);                         // dB += dCB^T C:  rows j (dCB^T), columns nn, k: i
     const int r = 16 * w + fr;
-    if (r < nrows) {
-        float *oc = dC + ((int64_t)b * L + l0 + r) * N + n0 + 4 * fq, *ob = dB + ((int64_t)b * L + l0 + r) * N + n0 + 4 * fq;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            st4c(oc + 16 * nt, make_float4(aC[nt][0], aC[nt][1], aC[nt][2], aC[nt][3]));
-            st4c(ob + 16 * nt, make_float4(aB[nt][0], aB[nt][1], aB[nt][2], aB[nt][3]));
+    for (int t = 0; t < NTW; ++t) {
+        if (t > 0) __syncthreads();
+        stage_tile(sB1, Bm + ((int64_t)b * L + l0) * N + n0 + t * kQc, N, nrows, tid);         // B[j][nn]
+        stage_tile(sA2, Cm + ((int64_t)b * L + l0) * N + n0 + t * kQc, N, nrows, tid);         // C[i][nn]
+        __syncthreads();
+        mma_16x64<false, true, false>(aC[t], sA1, 16 * w, sB1, nullptr, lane);                 // dC += dCB B:    rows i, columns nn (B^T of [j][nn]), k: j
+        mma_16x64<true, true, false>(aB[t], sA1, 16 * w, sA2, nullptr, lane);                  // dB += dCB^T C:  rows j (dCB^T), columns nn, k: i
+        if (r < nrows) {
+            float *oc = dC + ((int64_t)b * L + l0 + r) * N + n0 + t * kQc + 4 * fq, *ob = dB + ((int64_t)b * L + l0 + r) * N + n0 + t * kQc + 4 * fq;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                st4c(oc + 16 * nt, make_float4(aC[t][nt][0], aC[t][nt][1], aC[t][nt][2], aC[t][nt][3]));
+                st4c(ob + 16 * nt, make_float4(aB[t][nt][0], aB[t][nt][1], aB[t][nt][2], aB[t][nt][3]));
+            }
         }
     }
 }
@@ -577,8 +626,14 @@ int ssd_chunk_bwd_dispatch(const float *x, const float *dy, const float *B, cons
     const int nc = (L + kQc - 1) / kQc;
     hipLaunchKernelGGL(ssd_bwd_main_kernel, dim3((unsigned)((int64_t)batch * nc * H)), dim3(256), 0, s, x, dy, B, CB, dS, dtv, cum, decay, ddecay, A, D,
                        d_has_hdim, softplus, dcum_off, dx, ddt, dA, dbias, dD, dCB, L, nc, H, N);
-    hipLaunchKernelGGL(ssd_bwd_bc_kernel, dim3((unsigned)((int64_t)batch * nc * (N / kQc))), dim3(256), 0, s, x, dy, B, C, Sin, dS, dtv, cum, dCB, dB, dC,
-                       L, nc, H, N);
+    // state tiles per workgroup of the dB / dC kernel: as many as divide N / 64, up to 4, while the grid still covers the chip
+    const int ntl = N / kQc;
+    if (ntl % 4 == 0 && (int64_t)batch * nc * (ntl / 4) >= 512)
+        hipLaunchKernelGGL((ssd_bwd_bc_kernel<4>), dim3((unsigned)((int64_t)batch * nc * (ntl / 4))), dim3(256), 0, s, x, dy, B, C, Sin, dS, dtv, cum, dCB, dB, dC, L, nc, H, N);
+    else if (ntl % 2 == 0 && (int64_t)batch * nc * (ntl / 2) >= 512)
+        hipLaunchKernelGGL((ssd_bwd_bc_kernel<2>), dim3((unsigned)((int64_t)batch * nc * (ntl / 2))), dim3(256), 0, s, x, dy, B, C, Sin, dS, dtv, cum, dCB, dB, dC, L, nc, H, N);
+    else
+        hipLaunchKernelGGL((ssd_bwd_bc_kernel<1>), dim3((unsigned)((int64_t)batch * nc * ntl)), dim3(256), 0, s, x, dy, B, C, Sin, dS, dtv, cum, dCB, dB, dC, L, nc, H, N);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
