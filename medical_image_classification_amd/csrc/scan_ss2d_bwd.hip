@@ -15,8 +15,15 @@
 // state axis), d_state == 16, dense real A, 8-channel waves x 2 states per lane, no MS_SCAN_ACCUMULATE / BC_MAP / LATTICE.
 // Everything else stays on scan_bwd.hip.
 #include <cstdlib>
+#include <type_traits>
 #include "scan_common.h"
 
+#ifndef MS_BWD_FULLPATH
+#define MS_BWD_FULLPATH 0
+#endif
+#ifndef MS_BWD_LDSPF
+#define MS_BWD_LDSPF 0
+#endif
 #ifndef MS_BWD_W3_DEFAULT
 #define MS_BWD_W3_DEFAULT false
 #endif
@@ -156,23 +163,35 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
     int len_prev = 0;
 
     // the work of the PREVIOUS chunk (out / dB|dC tiles of parity pp, positions tabp) that rides inside the sweeps of the current one
-    auto store_du = [&](int pp) {
+    auto store_du = [&](int pp, auto fullp) {
         const float4 v = ld4b(sOut_[pp][wv][0] + pl * CW + q4);
-        if (pl < len_prev && quad_ok) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
+#ifdef MS_ABL_NOGST
+        if (pl < len_prev && quad_ok && v.x == 123.456f) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
+#else
+        if ((decltype(fullp)::value || pl < len_prev) && quad_ok) st4b(atb(dub, __mul24(pos_prev, du_sl) + q4), v);
+#endif
     };
-    auto store_dd = [&](int pp) {
+    auto store_dd = [&](int pp, auto fullp) {
         float4 v = ld4b(sOut_[pp][wv][1] + pl * CW + q4);
         v.x *= sig_prev.x; v.y *= sig_prev.y; v.z *= sig_prev.z; v.w *= sig_prev.w;       // d delta = d delta' * softplus'
-        if (pl < len_prev && quad_ok) {
+#ifdef MS_ABL_NOGST
+        if (pl < len_prev && quad_ok && v.x == 123.456f) {
+#else
+        if ((decltype(fullp)::value || pl < len_prev) && quad_ok) {
+#endif
             st4b(atb(ddb, __mul24(pos_prev, dd_sl) + q4), v);
             dbk[0] += v.x; dbk[1] += v.y; dbk[2] += v.z; dbk[3] += v.w;
         }
     };
-    auto flush_piece = [&](int pp, const int *tabp, int i) {
+    auto flush_piece = [&](int pp, const int *tabp, int i, auto fullp) {
         const float *src = sdBC_[pp][0] + fsrc + 8 * i;
         const float v = (src[0] + src[kWSb]) + (src[2 * kWSb] + src[3 * kWSb]);
         const int l = flb0 + 8 * i;
-        if (l < len_prev) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
+#ifdef MS_ABL_NOATOM
+        if (l < len_prev && v == 123.456f) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
+#else
+        if (decltype(fullp)::value || l < len_prev) atomicAdd(fbase + __mul24(tabp[l], fsl), v);
+#endif
     };
 
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
@@ -215,7 +234,11 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         // ONE barrier per chunk: (i) this chunk's tiles are staged, (ii) every wave has finished the sweeps of chunk ch + 1, whose
         // dB / dC tiles (other parity) are combined below, (iii) the position table of chunk ch - 1 is written
         __syncthreads();
+#ifdef MS_ABL_NOGLD
+        if (ch > 0 && ch == n_chunks + 5) prefetch(ch - 1);
+#else
         if (ch > 0) prefetch(ch - 1);                      // lands while this chunk is computed
+#endif
         const int *tabp = stab[(ch + 1) & 3];
 
         // ---------------- packed sweeps (same algebra as scan_bwd.hip) ----------------
@@ -224,44 +247,103 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         // (MedMamba-T stages 3 / 2) do not pay for 15 / 28 padded positions.  (One unpredicated basic block for the steady state was
         // measured as well, MS_BWD_FASTBLOCK in the history of this file: 3-4 % SLOWER -- the giant scheduling region raises the
         // register pressure to 256 with spills; the per-batch regions the guards create schedule better.)
+        // FULL: this chunk and the previous one are whole (the steady state of a long sequence): the batch guards, the `have_prev` tests
+        // and the length predicates of the stores / flush compile out -- 60 scalar / branch instructions per chunk, which cost this
+        // kernel nearly as much as vector ones (measured: +256 s_mov per chunk = +7.8 %, +256 dependent v_add = +8.4 %).  The batches
+        // stay separate scheduling regions (sched_barrier): one region per chunk needs more than 256 registers.
+        auto sweeps = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         v2f ap[W3 ? 1 : kCL], ckp[NB];
         const float *sBl = sB + sg * 2, *sCl = sC + sg * 2;          // this lane's state pair inside a position row
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
-            if (kb * 4 < len) {
+            if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
+            if (FULL || kb * 4 < len) {
 #pragma unroll
                 for (int l = kb * 4; l < kb * 4 + 4; ++l) {
                     if ((l & 3) == 0) ckp[l >> 2] = hp;
+#ifdef MS_ABL_NOLDS
+                    const v2f p1 = sP1[c], p2 = sP2[c];
+                    const v2f Bp = *reinterpret_cast<const v2f *>(sBl);
+#else
                     const v2f p1 = sP1[l * CW + c], p2 = sP2[l * CW + c];      // {delta', u}, {dout, delta' u}
                     const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPb);
+#endif
+#ifdef MS_ABL_NOEXP
+                    const v2f a = pk_fma((v2f){p1.x, p1.x}, A2p, (v2f){1.0f, 1.0f});
+#else
                     const v2f a = exp2_pk((v2f){p1.x, p1.x} * A2p);
+#endif
                     if constexpr (!W3) ap[l] = a;
                     hp = pk_fma(a, hp, (v2f){p2.y, p2.y} * Bp);
                 }
             }
-            if (have_prev) {                                       // wave-uniform
-                if (kb == 1) store_du(pp);
-                if (kb == 3) store_dd(pp);
+            if (FULL || have_prev) {                               // wave-uniform
+                if (kb == 1) store_du(pp, full_c);
+                if (kb == 3) store_dd(pp, full_c);
                 if (W3) {
-                    if (kb >= 4) flush_piece(pp, tabp, kb - 4);
+                    if (kb >= 4) flush_piece(pp, tabp, kb - 4, full_c);
                 } else {
-                    if (kb == 5) flush_piece(pp, tabp, 0);
-                    if (kb == 7) flush_piece(pp, tabp, 1);
+                    if (kb == 5) flush_piece(pp, tabp, 0, full_c);
+                    if (kb == 7) flush_piece(pp, tabp, 1, full_c);
                 }
             }
         }
         if constexpr (W3) __syncthreads();     // every wave has read the previous chunk's dB / dC tiles: the reverse sweep may overwrite them
+#if MS_BWD_LDSPF >= 1
+        // the LDS operands of a reverse batch are read ONE BATCH AHEAD (the compiler places a batch's reads at the top of its block and
+        // waits for them at once: three exposed LDS round trips per batch in the listing); the first batch's are read here
+        v2f nB[4], nP2[4];
+#if MS_BWD_LDSPF >= 2
+        v2f nC[4], nP1[4];
+#endif
+        {
+            const int lbf = FULL ? kCL - 4 : ((len - 1) >> 2) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nB[j] = *reinterpret_cast<const v2f *>(sBl + (lbf + j) * kRPb); nP2[j] = sP2[(lbf + j) * CW + c];
+#if MS_BWD_LDSPF >= 2
+                nC[j] = *reinterpret_cast<const v2f *>(sCl + (lbf + j) * kRPb); nP1[j] = sP1[(lbf + j) * CW + c];
+#endif
+            }
+        }
+#endif
 #pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            if (lb < len) {
+            if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
+            if (FULL || lb < len) {
                 v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4], aj[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#if MS_BWD_LDSPF >= 1
+                    Bp[j] = nB[j]; p2[j] = nP2[j];
+#elif defined(MS_ABL_NOLDS)
+                    Bp[j] = *reinterpret_cast<const v2f *>(sBl); p2[j] = sP2[c];
+#else
                     Bp[j] = *reinterpret_cast<const v2f *>(sBl + (lb + j) * kRPb);
+                    p2[j] = sP2[(lb + j) * CW + c];
+#endif
+#if MS_BWD_LDSPF >= 2
+                    Cp[j] = nC[j]; p1[j] = nP1[j];
+#elif defined(MS_ABL_NOLDS)
+                    Cp[j] = *reinterpret_cast<const v2f *>(sCl); p1[j] = sP1[c];
+#else
                     Cp[j] = *reinterpret_cast<const v2f *>(sCl + (lb + j) * kRPb);
-                    p1[j] = sP1[(lb + j) * CW + c]; p2[j] = sP2[(lb + j) * CW + c];
+                    p1[j] = sP1[(lb + j) * CW + c];
+#endif
                 }
+#if MS_BWD_LDSPF >= 1
+                if (kb > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        nB[j] = *reinterpret_cast<const v2f *>(sBl + (lb - 4 + j) * kRPb); nP2[j] = sP2[(lb - 4 + j) * CW + c];
+#if MS_BWD_LDSPF >= 2
+                        nC[j] = *reinterpret_cast<const v2f *>(sCl + (lb - 4 + j) * kRPb); nP1[j] = sP1[(lb - 4 + j) * CW + c];
+#endif
+                    }
+                }
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if constexpr (W3) aj[j] = exp2_pk((v2f){p1[j].x, p1[j].x} * A2p); else aj[j] = ap[lb + j];
@@ -269,48 +351,81 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                     hv[j] = pk_fma(aj[j], j > 0 ? hv[j > 0 ? j - 1 : 0] : ckp[kb], bu[j]);
                 }
                 float duv[4], ddv[4], vB8[8], vC8[8];
+#ifdef MS_ABL_ADDSNOP
+#pragma unroll
+                for (int z = 0; z < 32; ++z) asm volatile("s_nop 0");
+#endif
+#ifdef MS_ABL_ADDSALU
+#pragma unroll
+                for (int z = 0; z < 32; ++z) asm volatile("s_mov_b32 s90, 0" ::: "s90");
+#endif
+#ifdef MS_ABL_ADDVALU
+                { float zz = 0.f;
+#pragma unroll
+                for (int z = 0; z < 32; ++z) asm volatile("v_add_f32 %0, %0, %0" : "+v"(zz)); }
+#endif
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const v2f gg = {p2[j].x, p2[j].x};
                     const v2f dhn = pk_fma(Cp[j], gg, dhp);
-                    const v2f w = hv[j] - bu[j];                         // = a_j * h_{j-1}
                     const v2f t1 = dhn * Bp[j];
-                    const v2f qv = dhn * w;
+                    dhp = aj[j] * dhn;
+                    // a_j h_{j-1} dh_j as (a_j dh_j) h_{j-1}: the first factor is the carry that is formed anyway, h_{j-1} is at hand
+                    // (was dh_j * (h_j - b_j u_j): one more packed instruction per position)
+                    const v2f qv = dhp * (j > 0 ? hv[j > 0 ? j - 1 : 0] : ckp[kb]);
                     const v2f t2 = qv * Anp;
                     dAp = pk_fma(qv, (v2f){p1[j].x, p1[j].x}, dAp);
-                    // the dB / dC terms go to the DPP sums as separate scalars: plain v_mul_f32 with the scalar operand (a packed multiply
-                    // needs the splat in a register pair: two v_mov each, 96 per chunk in the ISA of the first version)
-                    vB8[2 * j] = dhn.x * p2[j].y; vB8[2 * j + 1] = dhn.y * p2[j].y;
-                    vC8[2 * j] = p2[j].x * hv[j].x; vC8[2 * j + 1] = p2[j].x * hv[j].y;
-                    dhp = aj[j] * dhn;
+                    {   // the dB / dC terms: packed multiplies, the scalar operand taken from one half of the staged pair by op_sel (written
+                        // as assembly: left to the compiler the splat is built with two v_mov per product -- 96 per chunk -- and as four
+                        // scalar multiplies it is two instructions more per position)
+                        v2f vb, vc;
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(vb) : "v"(dhn), "v"(p2[j]));          // dh * (delta' u)
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(vc) : "v"(hv[j]), "v"(p2[j]));     // h * dout
+                        vB8[2 * j] = vb.x; vB8[2 * j + 1] = vb.y; vC8[2 * j] = vc.x; vC8[2 * j + 1] = vc.y;
+                    }
                     const float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
-                    duv[j] = fmaf(s1, p1[j].x, Dv * p2[j].x);
-                    ddv[j] = fmaf(s1, p1[j].y, s2);
+                    // {du, d delta'} = s1 * {delta', u} + {D dout, s2}: one packed FMA on the staged pair
+                    const v2f o = pk_fma((v2f){s1, s1}, p1[j], (v2f){Dv * p2[j].x, s2});
+                    duv[j] = o.x; ddv[j] = o.y;
                 }
+#ifdef MS_ABL_NOGROUP
+                const float du_t = (duv[0] + duv[1]) + (duv[2] + duv[3]), dd_t = (ddv[0] + ddv[1]) + (ddv[2] + ddv[3]);
+#else
                 const float du_t = sum_groups_scatter4<CW>(duv, lane);
                 const float dd_t = sum_groups_scatter4<CW>(ddv, lane);
-                if (is_group_owner<CW>(lane)) {
+#endif
+                {   // both lanes of the last butterfly pair (lane bit 3) hold the total and store it to the same word: no predicate, and
+                    // the last DPP add stays in this block where it folds into one v_add_f32_dpp (behind `if (owner)` it was sunk into the
+                    // branch: v_mov_b32_dpp + v_add + an exec save / restore per batch)
                     const int lo = lb + group_slot<CW>(lane);
                     su[lo * CW + c] = du_t;
                     sgd[lo * CW + c] = dd_t;
                 }
+#ifdef MS_ABL_NOCHAN
+                sdB[t_dpp + lb] = ((vB8[0] + vB8[1]) + (vB8[2] + vB8[3])) + ((vB8[4] + vB8[5]) + (vB8[6] + vB8[7]));
+                sdC[t_dpp + lb] = ((vC8[0] + vC8[1]) + (vC8[2] + vC8[3])) + ((vC8[4] + vC8[5]) + (vC8[6] + vC8[7]));
+#else
                 sdB[t_dpp + lb] = chan_scatter8(vB8, lane);
                 sdC[t_dpp + lb] = chan_scatter8(vC8, lane);
+#endif
             }
-            if (!W3 && have_prev) {
-                if (kb == 5) flush_piece(pp, tabp, 2);
-                if (kb == 2) flush_piece(pp, tabp, 3);
+            if (!W3 && (FULL || have_prev)) {
+                if (kb == 5) flush_piece(pp, tabp, 2, full_c);
+                if (kb == 2) flush_piece(pp, tabp, 3, full_c);
             }
         }
+        };
+        if (MS_BWD_FULLPATH && len == kCL && have_prev && len_prev == kCL) sweeps(std::true_type{});
+        else sweeps(std::false_type{});
         sig_prev = sig_cur; pos_prev = pos_cur; len_prev = len;
     }
     // epilogue: chunk 0's stores and flush
     __syncthreads();
     {
         const int *tabp = stab[0];
-        store_du(0); store_dd(0);
+        store_du(0, std::false_type{}); store_dd(0, std::false_type{});
 #pragma unroll
-        for (int i = 0; i < 4; ++i) flush_piece(0, tabp, i);
+        for (int i = 0; i < 4; ++i) flush_piece(0, tabp, i, std::false_type{});
     }
 
     if (active) {

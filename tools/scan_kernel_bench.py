@@ -44,6 +44,9 @@ for si in which:
     Q.dout, Q.du, Q.ddelta = gy.data_ptr(), du4.data_ptr(), dd4.data_ptr()
     Q.dA, Q.dD, Q.ddelta_bias = dA.data_ptr(), dD.data_ptr(), db.data_ptr()
     Q.dB, Q.dC = dproj.data_ptr() + 4 * R, dproj.data_ptr() + 4 * (R + N)
+    if os.environ.get("KB_PRE", "1") == "1":     # what the training step launches: delta holds delta' = softplus(delta + bias) (MS_SCAN_DELTA_ACTIVATED)
+        delta.copy_(torch.nn.functional.softplus(delta + bias.view(4, 1, 1, D)))
+        P.delta_softplus |= 512; Q.f.delta_softplus |= 512
     st = _lib.current_stream_ptr(dev)
     def run(fn, arg):
         for _ in range(2):
