@@ -259,7 +259,10 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
                 y[j] = y2.x + y2.y;
             }
             const float yt = sum_groups_scatter4<CW>(y, lane);
-            if (is_group_owner<CW>(lane)) so[(lb + group_slot<CW>(lane)) * CW + c] = yt;
+            // 8-channel waves: both lanes of the last butterfly pair (lane bit 3) hold the total and store it to the same word -- no
+            // predicate, and the last DPP add folds into one v_add_f32_dpp (behind `if (owner)` it was a v_mov_b32_dpp + v_add inside
+            // an exec save / restore: 3 instructions more per batch)
+            so[(lb + group_slot<CW>(lane)) * CW + c] = yt;
         }
         };
         if (len == kCL) sweep(std::false_type()); else sweep(std::true_type());
