@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MEDSCAN_ABI_VERSION 8
+#define MEDSCAN_ABI_VERSION 9
 
 typedef enum MsStatus {
     MS_OK = 0,
@@ -451,6 +451,38 @@ int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H
 int ms_conv3x3_wgrad(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W, int Ci,
                      int Co, void *stream);
 int64_t ms_conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
+
+/* ---- the conv branch's inner BatchNorms folded into the convolutions around them (ABI v9) -------------------------------------------
+ * `conv3x3 -> BatchNorm2d -> ReLU -> conv3x3 -> BatchNorm2d -> ReLU` of SS_Conv_SSM.conv33conv33conv11 (MedMamba.py:518-524) in TRAINING
+ * mode: the statistics pass, the finalize launch and (for the inner BatchNorm) the apply pass of ms_bn_relu_nhwc_fwd disappear.
+ * MsBnFold describes ONE BatchNorm whose batch statistics travel from the convolution that produces its input (the PRODUCER, bn_out) to
+ * the kernel that consumes it (the CONSUMER: the next convolution's bn_in, or ms_bn_apply_sums_nhwc) as pivoted sums:
+ *   sums : MS_BN_REPLICAS x 2 x C floats, sum (y - p) and sum (y - p)^2 per channel over all pixels, split over replica rows (same-address
+ *          atomics serialise), followed by the C pivots p = running_mean - shift the producer used.  ZERO-FILLED by the caller before
+ *          the producer runs (MS_BN_FOLD_FLOATS(C) floats).
+ *   shift: the producing convolution's bias (may be NULL).  BN(conv + bias) == BN(conv) in training mode, so the bias never touches
+ *          the activation; it enters running_mean only (its gradient is identically zero).
+ *   the consumer writes save_mean / save_rstd (batch mean, 1 / sqrt(biased var + eps): what ms_bn_relu_nhwc_bwd takes), updates
+ *   running_mean / running_var (momentum; unbiased variance) and num_batches_tracked (may be NULL) exactly once. */
+#define MS_BN_REPLICAS 16
+#define MS_BN_FOLD_FLOATS(C) ((MS_BN_REPLICAS * 2 + 1) * (C))
+typedef struct MsBnFold {
+    float *sums;
+    const float *gamma, *beta, *shift;
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+    float *save_mean, *save_rstd;
+    float momentum, eps;
+} MsBnFold;
+/* ms_conv3x3_nhwc_bf16 with a BatchNorm folded into either side (both may be NULL: the plain convolution):
+ *   bn_in  : x is the PRE-BatchNorm activation (bf16); relu(bn_in(x)) is what is convolved, zero-padded AFTER the normalisation as the
+ *            module sequence does; `xhat` (bf16, like x; may be NULL) receives it -- the conv input the weight gradient needs.  Ci <= 512.
+ *   bn_out : the statistics of y (as stored, bf16-rounded) are accumulated into bn_out->sums. */
+int ms_conv3x3_bn_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
+                            const MsBnFold *bn_out, void *stream);
+/* The consumer for a BatchNorm that is not followed by a 3x3 convolution: y = [relu](bn(x)) from the producer's sums, one pass over
+ * x (npix, C) bf16 -> y (npix, C) bf16; also writes save_mean / save_rstd and updates the running statistics. */
+int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream);
 
 /* Diagnostic: force the workgroup tile of ms_gemm_bf16 (rows 64 / 128, columns 64 / 128 / 192; 0 = the built-in heuristic). */
 int ms_debug_gemm_tile(int block_rows, int block_cols);

@@ -9,6 +9,8 @@
                       (MedMamba.py:515,534-538,486-499) in one pass; the residual's gradient is `dout` itself
 All need CUDA (HIP) tensors and raise RuntimeError otherwise -- no CPU fallback.
 """
+import ctypes
+
 import torch
 
 from . import _lib, arena, shadow
@@ -463,6 +465,99 @@ def conv1x1_relu(conv, x, premasked=False):
         return _Conv1x1ReLU.apply(x, conv.weight, conv.bias, premasked)
 
 
+# ---- conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> ReLU with the two BatchNorms folded into the convolutions (csrc/conv3x3.hip, ABI v9) ----------
+_BN_FOLD = __import__("os").environ.get("MEDSCAN_CONV_BN_FOLD", "1") == "1"
+FOLD_CALLS = 0          # how often conv_branch took the folded form (tests)
+
+
+def _bn_fold_desc(sums, gamma, beta, shift, bn, save):
+    d = _lib.MsBnFold()
+    d.sums, d.gamma, d.beta = sums.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    d.num_batches_tracked = bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None
+    d.save_mean, d.save_rstd = save[0].data_ptr(), save[1].data_ptr()
+    d.momentum, d.eps = float(bn.momentum), float(bn.eps)
+    return d
+
+
+class _ConvBnConvBn(torch.autograd.Function):
+    """x2 = relu(bn2(conv2(relu(bn1(conv1(x0)))))) for training-mode BatchNorms on a bf16 channels_last activation
+    (`conv33conv33conv11[1:7]`, MedMamba.py:518-524) in THREE launches: conv1 accumulates the statistics of its output in its epilogue;
+    conv2 normalises + rectifies conv1's output while it stages its input tiles (writing the normalised activation `x1` as a side
+    output for the backward) and accumulates the statistics of ITS output; one apply pass produces x2.  Was 2 convolutions + 2 x
+    (statistics, finalize, apply).  The backward is the unfused one (BatchNorm backward kernels on the saved pre-BN activations, the
+    convolutions' input / weight gradient kernels on the saved conv inputs).  The conv biases never touch the activations (a constant
+    in front of a mean subtraction): they enter the running means only and get exact zero gradients."""
+
+    @staticmethod
+    def forward(ctx, x0, w1, b1, g1, be1, w2, b2, g2, be2, bn1, bn2):
+        B, C, H, W = x0.shape
+        lib = _lib.lib()
+        wb1, wb2 = shadow.bf16(w1, conv=True), shadow.bf16(w2, conv=True)
+        f32 = lambda t: t.detach().float().contiguous()
+        g1f, be1f, g2f, be2f = f32(g1), f32(be1), f32(g2), f32(be2)
+        b1f, b2f = (f32(b1) if b1 is not None else None), (f32(b2) if b2 is not None else None)
+        nf = (2 * _lib.BN_REPLICAS + 1) * C
+        sums = torch.zeros(2 * nf, device=x0.device, dtype=torch.float32)
+        save = torch.empty((4, C), device=x0.device, dtype=torch.float32)
+        new = lambda: torch.empty((B, C, H, W), device=x0.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        y1, x1, y2, x2 = new(), new(), new(), new()
+        d1 = _bn_fold_desc(sums[:nf], g1f, be1f, b1f, bn1, save[0:2])
+        d2 = _bn_fold_desc(sums[nf:], g2f, be2f, b2f, bn2, save[2:4])
+        st = _stream(x0)
+        with _lib.on_device(x0.device):
+            _lib.check(lib.ms_conv3x3_bn_nhwc_bf16(x0.data_ptr(), wb1.data_ptr(), y1.data_ptr(), B, H, W, C, C, None, None, ctypes.byref(d1), st),
+                       "ms_conv3x3_bn_nhwc_bf16")
+            _lib.check(lib.ms_conv3x3_bn_nhwc_bf16(y1.data_ptr(), wb2.data_ptr(), y2.data_ptr(), B, H, W, C, C, ctypes.byref(d1), x1.data_ptr(),
+                                                   ctypes.byref(d2), st), "ms_conv3x3_bn_nhwc_bf16")
+            _lib.check(lib.ms_bn_apply_sums_nhwc(y2.data_ptr(), ctypes.byref(d2), 1, x2.data_ptr(), B * H * W, C, st), "ms_bn_apply_sums_nhwc")
+        ctx.save_for_backward(x0, y1, x1, y2, g1f, be1f, g2f, be2f, save)
+        ctx.w1, ctx.w2, ctx.b1, ctx.b2 = w1, w2, b1, b2
+        ctx.dtypes = (g1.dtype, be1.dtype, g2.dtype, be2.dtype)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x0, y1, x1, y2, g1f, be1f, g2f, be2f, save = ctx.saved_tensors
+        B, C, H, W = x0.shape
+        shadow.invalidate(x0.device)
+        lib = _lib.lib()
+        if dx2.dtype not in (torch.float32, torch.bfloat16):
+            dx2 = dx2.float()
+        dx2 = dx2.contiguous(memory_format=torch.channels_last)
+
+        def bn_bwd(xpre, dy, g, b, sv):
+            dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+            dgb = torch.empty((2, C), device=dy.device, dtype=torch.float32)
+            with _lib.on_device(dy.device):
+                _lib.check(lib.ms_bn_relu_nhwc_bwd(xpre.data_ptr(), 1, C, dy.data_ptr(), int(dy.dtype == torch.bfloat16), g.data_ptr(), b.data_ptr(),
+                                                   sv[0].data_ptr(), sv[1].data_ptr(), 1, dx.data_ptr(), 1, dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                                   _bn_scratch(dy.device, C).data_ptr(), B * H * W, C, _stream(dy)), "ms_bn_relu_nhwc_bwd")
+            return dx, dgb
+
+        dy2, dgb2 = bn_bwd(y2, dx2, g2f, be2f, save[2:4])
+        dw2 = _conv3x3_wgrad(x1, dy2, ctx.w2.shape) if ctx.needs_input_grad[5] else None
+        dx1 = _conv3x3_direct(dy2, shadow.bf16(ctx.w2, conv="flip", in_backward=True))
+        dy1, dgb1 = bn_bwd(y1, dx1, g1f, be1f, save[0:2])
+        dw1 = _conv3x3_wgrad(x0, dy1, ctx.w1.shape) if ctx.needs_input_grad[1] else None
+        dx0 = _conv3x3_direct(dy1, shadow.bf16(ctx.w1, conv="flip", in_backward=True)) if ctx.needs_input_grad[0] else None
+        t1, t2, t3, t4 = ctx.dtypes
+        zb = lambda b: arena.zeros_like(b) if b is not None else None           # d/d(conv bias) of BN(conv + bias) == 0
+        return (dx0, dw1, zb(ctx.b1), dgb1[0].to(t1), dgb1[1].to(t2), dw2, zb(ctx.b2), dgb2[0].to(t3), dgb2[1].to(t4), None, None)
+
+
+def _conv_bn_fold_ok(c1, bn1, c2, bn2, x):
+    def bn_ok(bn):
+        return (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and type(bn) is torch.nn.BatchNorm2d
+                and bn.running_mean is not None and bn.weight.dtype == torch.float32)
+    def conv_ok(c):
+        return (type(c) is torch.nn.Conv2d and c.padding_mode == "zeros" and c.groups == 1 and c.weight.dtype == torch.float32
+                and _conv3x3_direct_ok(x, c.weight, c.stride, c.padding, c.dilation) and c.in_channels == c.out_channels == x.shape[1])
+    return (_BN_FOLD and _CONV_WGRAD and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] <= 512 and bn_ok(bn1) and bn_ok(bn2)
+            and conv_ok(c1) and conv_ok(c2) and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 def conv_branch(seq, x, premasked_out=False):
     """The conv branch of SS_Conv_SSM (`self.conv33conv33conv11`, MedMamba.py:517-527) applied module by module with each
     BatchNorm2d (+ following ReLU) fused: BN -> conv3x3 -> BN+ReLU -> conv3x3 -> BN+ReLU -> conv1x1 -> ReLU.  Falls back to
@@ -476,8 +571,15 @@ def conv_branch(seq, x, premasked_out=False):
         y = seq(x.contiguous(memory_format=torch.channels_last))
         return (y, False) if premasked_out else y
     x = batchnorm_relu(mods[0], x, False)
-    x = _conv_then_bn(mods[1], mods[2], x)
-    x = _conv_then_bn(mods[4], mods[5], x)
+    if _conv_bn_fold_ok(mods[1], mods[2], mods[4], mods[5], x):
+        global FOLD_CALLS
+        FOLD_CALLS += 1
+        with torch.autocast(device_type="cuda", enabled=False):
+            x = _ConvBnConvBn.apply(x, mods[1].weight, mods[1].bias, mods[2].weight, mods[2].bias, mods[4].weight, mods[4].bias,
+                                    mods[5].weight, mods[5].bias, mods[2], mods[5])
+    else:
+        x = _conv_then_bn(mods[1], mods[2], x)
+        x = _conv_then_bn(mods[4], mods[5], x)
     y = conv1x1_relu(mods[7], x, premasked=premasked_out)
     if y is not None:
         return (y, True) if premasked_out else y

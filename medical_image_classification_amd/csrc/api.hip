@@ -40,6 +40,9 @@ int block_head_bwd_dispatch(const float *dout, const void *dl, int dl_is_bf16, c
                             int64_t npix, int C, hipStream_t s);
 void gemm_debug_tile(int bm, int bn);
 int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, hipStream_t s);
+int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
+                             const MsBnFold *bn_out, hipStream_t s);
+int bn_apply_sums_dispatch(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, hipStream_t s);
 int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W,
                            int Ci, int Co, hipStream_t s);
 int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
@@ -136,6 +139,15 @@ int ms_gemm_bf16_wgrad_bias(const void *dy, int dy_is_f32, int64_t lddy, const v
 
 int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream) {
     return ms::conv3x3_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, (hipStream_t)stream);
+}
+
+int ms_conv3x3_bn_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
+                            const MsBnFold *bn_out, void *stream) {
+    return ms::conv3x3_bn_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, bn_in, xhat, bn_out, (hipStream_t)stream);
+}
+
+int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream) {
+    return ms::bn_apply_sums_dispatch(x, bn, relu, y, npix, C, (hipStream_t)stream);
 }
 
 int ms_conv3x3_wgrad(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W, int Ci,

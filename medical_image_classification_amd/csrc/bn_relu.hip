@@ -223,6 +223,36 @@ bn_bwd_apply_kernel(const T *__restrict__ x, int64_t xps, const TG *__restrict__
     }
 }
 
+// apply for a BatchNorm whose statistics arrive as the replica rows of pivoted sums a convolution's epilogue accumulated (MsBnFold,
+// conv3x3.hip): every thread derives its channel's scale / shift from the rows (2 x MS_BN_REPLICAS loads, L2-resident), then the
+// same pass as bn_apply_kernel; the first row of workgroups also writes mean / rstd for the backward and updates the running statistics
+__global__ void __launch_bounds__(kBnThreads)
+bn_apply_sums_kernel(const unsigned short *__restrict__ x, const float *__restrict__ sums, const float *__restrict__ gamma,
+                     const float *__restrict__ beta, const float *__restrict__ shift, float *__restrict__ running_mean,
+                     float *__restrict__ running_var, long long *__restrict__ nbt, float *__restrict__ save_mean, float *__restrict__ save_rstd,
+                     float momentum, float eps, int relu, unsigned short *__restrict__ y, int64_t npix, int C, int ct, int rpi) {
+    const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    float a = 0.0f, b2 = 0.0f;
+#pragma unroll 4
+    for (int r = 0; r < MS_BN_REPLICAS; ++r) { a += sums[(r * 2) * C + c]; b2 += sums[(r * 2 + 1) * C + c]; }
+    const float inv_n = 1.0f / (float)npix, m1 = a * inv_n, var = fmaxf(fmaf(-m1, m1, b2 * inv_n), 0.0f);
+    const float mean = sums[MS_BN_REPLICAS * 2 * C + c] + m1, rstd = rsqrtf(var + eps);
+    const float g = gamma[c] * rstd, b = beta[c] - mean * g;
+    if (blockIdx.x == 0 && r0 == 0) {
+        save_mean[c] = mean; save_rstd[c] = rstd;
+        const float sh = shift ? shift[c] : 0.0f, unb = npix > 1 ? var * ((float)npix / (float)(npix - 1)) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (mean + sh);
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unb;
+    }
+    for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
+        float v = fmaf(bn_ld(x + p * C + c), g, b);
+        if (relu) v = fmaxf(v, 0.0f);
+        bn_st(y + p * C + c, v);
+    }
+}
+
 static unsigned bn_blocks(int64_t npix, int rpi) {
     const int64_t need = (npix + (int64_t)rpi * 8 - 1) / ((int64_t)rpi * 8);         // >= 8 rows per thread
     return (unsigned)(need < 1 ? 1 : (need > kBnMaxBlocks ? kBnMaxBlocks : need));
@@ -249,6 +279,19 @@ int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, 
     if (x_bf16 && y_bf16) MS_BN_APPLY(bf, bf); else if (x_bf16) MS_BN_APPLY(bf, float);
     else if (y_bf16) MS_BN_APPLY(float, bf); else MS_BN_APPLY(float, float);
 #undef MS_BN_APPLY
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int bn_apply_sums_dispatch(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, hipStream_t s) {
+    if (!x || !y || !bn || !bn->sums || !bn->gamma || !bn->beta || !bn->running_mean || !bn->running_var || !bn->save_mean || !bn->save_rstd)
+        return MS_ERR_NULL;
+    if (npix <= 0 || C <= 0) return npix == 0 && C > 0 ? MS_OK : MS_ERR_SHAPE;
+    const BnGeom g = bn_geom(C);
+    const unsigned nblk = bn_blocks(npix, g.rows_per_iter);
+    using bf = unsigned short;
+    hipLaunchKernelGGL(bn_apply_sums_kernel, dim3(nblk, (unsigned)g.ncb), dim3(kBnThreads), 0, s, (const bf *)x, bn->sums, bn->gamma, bn->beta, bn->shift,
+                       bn->running_mean, bn->running_var, (long long *)bn->num_batches_tracked, bn->save_mean, bn->save_rstd, bn->momentum, bn->eps,
+                       relu, (bf *)y, npix, C, g.ct, g.rows_per_iter);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

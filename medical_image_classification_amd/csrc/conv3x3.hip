@@ -24,6 +24,36 @@ constexpr int kWP = kKS + 8;                     // weight row pitch (bf16)
 }
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- training-mode BatchNorm folded into the convolution on both sides (MedMamba.py:518-524: conv3x3 -> BatchNorm2d -> ReLU -> conv3x3 -> ...) --
+// STATS (producer side): the epilogue accumulates, per output channel, sum (y - p) and sum (y - p)^2 of the bf16-ROUNDED outputs it stores
+//   (p = running_mean - conv bias: a pivot near the batch mean once training runs, any value is valid) into one of kBnRep replica rows of
+//   `sums` with fp32 atomics (replicas: 1 792 workgroups adding to one address serialise at the memory side); the statistics and finalize
+//   launches of that BatchNorm disappear.
+// BNIN (consumer side): the input tensor is the PRE-BatchNorm activation; every workgroup derives scale / shift of all input channels
+//   from the replica rows while its first slice's loads are in flight, applies relu(x * scale + shift) to the halo pieces on their way
+//   from registers to LDS (out-of-image pixels stay zero: the convolution pads the NORMALISED activation), and the workgroups of the
+//   first output-channel block write the normalised interior of their tile to `xhat` (what the backward's weight gradient reads), so the
+//   apply pass (a read and a write of the activation) disappears too.  Workgroup (0, 0) writes the batch mean / rstd for the backward and
+//   updates the running statistics (torch semantics: biased variance to normalise, unbiased into running_var).
+constexpr int kBnRep = MS_BN_REPLICAS;
+constexpr int kBnMaxC = 512;                     // input channels whose scale / shift fit the LDS tables
+struct BnFoldDev {
+    float *sums;                                 // [kBnRep][2][C] sums, then [C] pivots
+    const float *gamma, *beta, *shift;
+    float *running_mean, *running_var;
+    long long *nbt;
+    float *save_mean, *save_rstd;
+    float momentum, eps, inv_n, unbias;          // inv_n = 1 / pixels, unbias = n / (n - 1)
+};
+__device__ __forceinline__ float bf_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned bf_pack(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+template <int CTRL> __device__ __forceinline__ float row_ror_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, x), CTRL, 0xF, 0xF, true));
+}
 // MS_CONV_PF2 = 1: two slices of prefetch distance through a second register set (182 VGPRs: two workgroups per CU instead of
 // three).  Measured 34.6 / 29.8 / 26.0 / 41.8 us cold at stages 0-3 against 31.8 / 27.5 / 25.8 / 41.0 with one set at three
 // workgroups per CU: off.
@@ -40,13 +70,15 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // first version ran `load -> LDS store` loops with run-time trip counts: ten dependent global-load round trips per slice, which
 // -- not the MFMAs, not LDS -- were the kernel's time.)  Slices of 32 channels use v_mfma_f32_16x16x32_bf16 (one ds_read_b128 per
 // fragment), a 16-channel tail slice the K = 16 form.
-template <int NB>
+template <int NB, bool BNIN = false, bool STATS = false>
 // (NB = 4, MedMamba-B's 64-channel blocks: 60 KB of LDS and 3 x 16 accumulator registers more -- two workgroups per CU is what fits)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB >= 4 ? 2 : MS_CONV_WAVES, NB >= 4 ? 2 : MS_CONV_WAVES)))
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
-                    int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img) {
+                    int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img, BnFoldDev bin, unsigned short *__restrict__ xhat,
+                    BnFoldDev bout) {
     __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kXP];
     __shared__ __attribute__((aligned(16))) unsigned short sW[9 * NB * 16 * kWP];
+    __shared__ __attribute__((aligned(16))) float sScale[BNIN ? kBnMaxC : 4], sShift[BNIN ? kBnMaxC : 4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile = blockIdx.x, img = tile / tiles_per_img, tt = tile - img * tiles_per_img;
     const int h0 = (tt / tiles_w) * kTH, w0 = (tt % tiles_w) * kTW;
@@ -97,13 +129,29 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             if (row < 9 * NB * 16 && co0 + col < Co) rw[i] = *reinterpret_cast<const uint4 *>(w + ((int64_t)(co0 + col) * 9 + tap) * Ci + k0 + pc * 8);
         }
     };
-    auto put = [&](const uint4 (&rx)[kNX], const uint4 (&rw)[kNW], int ks) {
+    auto put = [&](const uint4 (&rx)[kNX], const uint4 (&rw)[kNW], int ks, int k0) {
         const int psh = ks == kKS ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
             int pix, pc;
             item(tid + i * 256, psh, pix, pc);
-            if (pix < kHH * kHW) *reinterpret_cast<uint4 *>(sX + pix * kXP + pc * 8) = rx[i];
+            uint4 v = rx[i];
+            if constexpr (BNIN) {
+                const int ph = pix / kHW, pw = pix - ph * kHW, hh = h0 - 1 + ph, ww = w0 - 1 + pw;
+                const bool ok = pix < kHH * kHW && hh >= 0 && hh < H && ww >= 0 && ww < W;
+                const int c8 = k0 + pc * 8;
+                const float4 s0 = *reinterpret_cast<const float4 *>(sScale + c8), s1 = *reinterpret_cast<const float4 *>(sScale + c8 + 4);
+                const float4 t0 = *reinterpret_cast<const float4 *>(sShift + c8), t1 = *reinterpret_cast<const float4 *>(sShift + c8 + 4);
+                v.x = bf_pack(fmaxf(fmaf(bf_lo(v.x), s0.x, t0.x), 0.f), fmaxf(fmaf(bf_hi(v.x), s0.y, t0.y), 0.f));
+                v.y = bf_pack(fmaxf(fmaf(bf_lo(v.y), s0.z, t0.z), 0.f), fmaxf(fmaf(bf_hi(v.y), s0.w, t0.w), 0.f));
+                v.z = bf_pack(fmaxf(fmaf(bf_lo(v.z), s1.x, t1.x), 0.f), fmaxf(fmaf(bf_hi(v.z), s1.y, t1.y), 0.f));
+                v.w = bf_pack(fmaxf(fmaf(bf_lo(v.w), s1.z, t1.z), 0.f), fmaxf(fmaf(bf_hi(v.w), s1.w, t1.w), 0.f));
+                if (!ok) v = make_uint4(0, 0, 0, 0);
+                // the tile's own pixels (not the halo ring), once per tile: the first output-channel block's workgroup
+                if (xhat != nullptr && blockIdx.y == 0 && ok && ph >= 1 && ph <= kTH && pw >= 1 && pw <= kTW)
+                    *reinterpret_cast<uint4 *>(xhat + (((int64_t)img * H + hh) * W + ww) * Ci + c8) = v;
+            }
+            if (pix < kHH * kHW) *reinterpret_cast<uint4 *>(sX + pix * kXP + pc * 8) = v;
         }
 #pragma unroll
         for (int i = 0; i < kNW; ++i) {
@@ -156,13 +204,13 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
     if (kKS < Ci) fetch(rxb, rwb, kKS);
     for (int k0 = 0; k0 < Ci; k0 += 2 * kKS) {
         __syncthreads();
-        put(rxa, rwa, min(kKS, Ci - k0));
+        put(rxa, rwa, min(kKS, Ci - k0), k0);
         __syncthreads();
         if (k0 + 2 * kKS < Ci) fetch(rxa, rwa, k0 + 2 * kKS);
         mac(min(kKS, Ci - k0));
         if (k0 + kKS < Ci) {
             __syncthreads();
-            put(rxb, rwb, min(kKS, Ci - k0 - kKS));
+            put(rxb, rwb, min(kKS, Ci - k0 - kKS), k0 + kKS);
             __syncthreads();
             if (k0 + 3 * kKS < Ci) fetch(rxb, rwb, k0 + 3 * kKS);
             mac(min(kKS, Ci - k0 - kKS));
@@ -170,10 +218,29 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
     }
 #else
     fetch(rxa, rwa, 0);
+    if constexpr (BNIN) {
+        // scale / shift of every input channel from the replica rows (the first slice's loads are in flight meanwhile)
+        for (int c = tid; c < Ci; c += 256) {
+            float a = 0.f, b = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < kBnRep; ++r) { a += bin.sums[(r * 2) * Ci + c]; b += bin.sums[(r * 2 + 1) * Ci + c]; }
+            const float m1 = a * bin.inv_n, var = fmaxf(fmaf(-m1, m1, b * bin.inv_n), 0.f);
+            const float mean = bin.sums[kBnRep * 2 * Ci + c] + m1, rstd = rsqrtf(var + bin.eps);
+            const float sc = bin.gamma[c] * rstd;
+            sScale[c] = sc; sShift[c] = fmaf(-mean, sc, bin.beta[c]);
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                bin.save_mean[c] = mean; bin.save_rstd[c] = rstd;
+                const float sh = bin.shift ? bin.shift[c] : 0.f;             // the layer's logical input is x + shift (the conv bias)
+                bin.running_mean[c] = (1.f - bin.momentum) * bin.running_mean[c] + bin.momentum * (mean + sh);
+                bin.running_var[c] = (1.f - bin.momentum) * bin.running_var[c] + bin.momentum * var * bin.unbias;
+            }
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && bin.nbt) *bin.nbt += 1;
+    }
     for (int k0 = 0; k0 < Ci; k0 += kKS) {
         const int ks = min(kKS, Ci - k0);                       // channels in this slice: 32, or a 16-channel tail
-        __syncthreads();                                        // the previous slice's fragments have been read
-        put(rxa, rwa, ks);
+        __syncthreads();                                        // the previous slice's fragments have been read (first trip: the tables are written)
+        put(rxa, rwa, ks, k0);
         __syncthreads();
         if (k0 + kKS < Ci) fetch(rxa, rwa, k0 + kKS);           // in flight during the products below
         mac(ks);
@@ -197,6 +264,60 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             }
         }
     }
+    if constexpr (STATS) {
+        // per output channel: sum (y - p), sum (y - p)^2 over the tile's in-image pixels, y as stored (bf16-rounded)
+        float s1[NB][4], s2[NB][4], pv[NB][4];
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = co0 + n * 16 + fq * 4 + r;
+                pv[n][r] = c < Co ? bout.running_mean[c] - (bout.shift ? bout.shift[c] : 0.f) : 0.f;
+                s1[n][r] = 0.f; s2[n][r] = 0.f;
+            }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const bool valid = h0 + wv * 2 + m < H && w0 + fr < W;
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float yv = (float)(__bf16)acc[m][n][r];
+                    const float d = valid ? yv - pv[n][r] : 0.f;
+                    s1[n][r] += d; s2[n][r] = fmaf(d, d, s2[n][r]);
+                }
+        }
+        // sum over the 16 pixel lanes of a row (lane bits 0-3): four row rotations, every lane ends with the row's total
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[n][r] = row_ror_add<0x121>(row_ror_add<0x122>(row_ror_add<0x124>(row_ror_add<0x128>(s1[n][r]))));
+                s2[n][r] = row_ror_add<0x121>(row_ror_add<0x122>(row_ror_add<0x124>(row_ror_add<0x128>(s2[n][r]))));
+            }
+        __syncthreads();                                        // every wave has read its last fragments: sX is free
+        float *red = reinterpret_cast<float *>(sX);             // [wave][2][NB * 16]
+        if (fr == 0) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wv * 2 + 0) * (NB * 16) + n * 16 + fq * 4 + r] = s1[n][r];
+                    red[(wv * 2 + 1) * (NB * 16) + n * 16 + fq * 4 + r] = s2[n][r];
+                }
+        }
+        __syncthreads();
+        if (tid < 2 * NB * 16) {
+            const int st = tid / (NB * 16), c = tid - st * (NB * 16);
+            if (co0 + c < Co) {
+                const float v = (red[(0 * 2 + st) * (NB * 16) + c] + red[(1 * 2 + st) * (NB * 16) + c]) +
+                                (red[(2 * 2 + st) * (NB * 16) + c] + red[(3 * 2 + st) * (NB * 16) + c]);
+                atomicAdd(bout.sums + ((blockIdx.x % kBnRep) * 2 + st) * Co + co0 + c, v);
+                if (blockIdx.x == 0 && st == 0)                 // the pivot these sums are taken around, for the consumer
+                    bout.sums[kBnRep * 2 * Co + co0 + c] = bout.running_mean[co0 + c] - (bout.shift ? bout.shift[co0 + c] : 0.f);
+            }
+        }
+    }
 }
 
 int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, hipStream_t s) {
@@ -210,8 +331,46 @@ int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int 
     const int cb = (Co % 64 == 0 && Co % 48 != 0) ? 64 : 48;
     const dim3 grid((unsigned)(batch * tiles_per_img), (unsigned)((Co + cb - 1) / cb));
     using bf = unsigned short;
-    if (cb == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<4>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img);
-    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<3>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img);
+    const BnFoldDev none = {};
+    if (cb == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<4>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none);
+    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<3>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+static bool bn_fold_ok(const MsBnFold *f) {
+    return f->sums && f->gamma && f->beta && f->running_mean && f->running_var && f->save_mean && f->save_rstd;
+}
+static BnFoldDev bn_fold_dev(const MsBnFold *f, int64_t npix) {
+    BnFoldDev d = {};
+    if (!f) return d;
+    d.sums = f->sums; d.gamma = f->gamma; d.beta = f->beta; d.shift = f->shift; d.running_mean = f->running_mean;
+    d.running_var = f->running_var; d.nbt = (long long *)f->num_batches_tracked; d.save_mean = f->save_mean; d.save_rstd = f->save_rstd;
+    d.momentum = f->momentum; d.eps = f->eps; d.inv_n = 1.0f / (float)npix; d.unbias = npix > 1 ? (float)npix / (float)(npix - 1) : 1.0f;
+    return d;
+}
+
+// The same convolution with a training-mode BatchNorm folded into its input side (bn_in: x is the PRE-BatchNorm tensor, relu(bn(x)) is
+// convolved and, when xhat != NULL, also written out) and / or its output side (bn_out: the statistics of y go to bn_out->sums).
+int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in,
+                             void *xhat, const MsBnFold *bn_out, hipStream_t s) {
+    if (!x || !w || !y) return MS_ERR_NULL;
+    if ((bn_in && !bn_fold_ok(bn_in)) || (bn_out && !bn_fold_ok(bn_out))) return MS_ERR_NULL;
+    if (batch < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0) return MS_ERR_SHAPE;
+    if (bn_in && Ci > kBnMaxC) return MS_ERR_UNSUPPORTED;
+    if (batch == 0) return MS_OK;
+    if (!bn_in && !bn_out) return conv3x3_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, s);
+    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH;
+    const int tiles_per_img = tiles_w * tiles_h;
+    const int cb = (Co % 64 == 0 && Co % 48 != 0) ? 64 : 48;
+    const dim3 grid((unsigned)(batch * tiles_per_img), (unsigned)((Co + cb - 1) / cb));
+    using bf = unsigned short;
+    const int64_t npix = (int64_t)batch * H * W;
+    const BnFoldDev di = bn_fold_dev(bn_in, npix), dz = bn_fold_dev(bn_out, npix);
+#define MS_CONV_BN(NBv, I, O) hipLaunchKernelGGL((conv3x3_nhwc_kernel<NBv, I, O>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, \
+        tiles_w, tiles_per_img, di, (bf *)xhat, dz)
+    if (cb == 64) { if (bn_in && bn_out) MS_CONV_BN(4, true, true); else if (bn_in) MS_CONV_BN(4, true, false); else MS_CONV_BN(4, false, true); }
+    else          { if (bn_in && bn_out) MS_CONV_BN(3, true, true); else if (bn_in) MS_CONV_BN(3, true, false); else MS_CONV_BN(3, false, true); }
+#undef MS_CONV_BN
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
