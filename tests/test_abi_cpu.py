@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(lib):
             "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd"} <= declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in medscan.h but not exported"
-    assert lib.ms_abi_version() == 8
+    assert lib.ms_abi_version() == 9
     assert lib.ms_scan_n_chunks(3136) == 98 and lib.ms_scan_n_chunks(49) == 2 and lib.ms_scan_n_chunks(0) == 0
     assert lib.ms_status_string(-3).decode() == "unsupported state dimension"
 
