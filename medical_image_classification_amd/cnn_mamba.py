@@ -554,6 +554,17 @@ def ssd_scan_merge(mod, xc):
     return _PixelsFromSeq.apply(y.reshape(B, L, K, mod.d_ssm), H, W).view(B, H, W, -1)
 
 
+def proj(lin, x):
+    """`lin(x)` for the bias-free token projections of the SSD blocks (CNN_Mamba.py:441-449,489,564; CrossMamba_fusion_2b2.py:142-160):
+    this package's GEMMs (ms_gemm_bf16 under bf16 autocast, ms_gemm_f32 in fp32 -- ss2d_ops.linear_splitk) instead of the library's."""
+    # both widths multiples of 8: rows of x, W, dy (and of W^T in the fp32 form) are then whole 16-byte pieces, which is what the kernels
+    # read; e.g. in_proj of the first two stages (290 / 548 outputs) stays on the library
+    if lin.bias is None and x.is_cuda and lin.weight.shape[0] % 8 == 0 and lin.weight.shape[1] % 8 == 0:
+        from .ss2d_ops import linear_splitk
+        return linear_splitk(x, lin.weight)
+    return lin(x)
+
+
 def ssd_tail(mod, out, z, z0, x0, d_mlp):
     """RMSNormGated, optional gated-MLP concat, out_proj, dropout (CNN_Mamba.py:554-564)."""
     if mod.rmsnorm:
@@ -562,7 +573,7 @@ def ssd_tail(mod, out, z, z0, x0, d_mlp):
         out = mod.norm(out, z, out_dtype=torch.bfloat16 if bf16 else None)
     if d_mlp > 0:
         out = torch.cat([F.silu(z0) * x0, out], dim=-1)
-    out_data = mod.out_proj(out)
+    out_data = proj(mod.out_proj, out)
     if mod.dropout is not None:
         out_data = mod.dropout(out_data)
     return out_data
@@ -650,7 +661,7 @@ class SS2D_with_SSD(nn.Module):
         B, H, W, C = u.shape
         L, K = H * W, 4
         GN = self.ngroups * self.d_state
-        zxbcdt = self.in_proj(u)
+        zxbcdt = proj(self.in_proj, u)
         d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * GN - self.nheads) // 2
         z0, x0, z, xBCdt = torch.split(zxbcdt, [d_mlp, d_mlp, self.d_ssm, self.d_ssm + 2 * GN + self.nheads], dim=-1)
         # depthwise conv + SiLU over the whole [x | B | C | dt] stack (dt goes through the conv too, CNN_Mamba.py:490-491),

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .cnn_mamba import RMSNormGated, SS2D_with_SSD, ssd_dwconv_silu, ssd_scan_merge, ssd_tail
+from .cnn_mamba import RMSNormGated, SS2D_with_SSD, proj, ssd_dwconv_silu, ssd_scan_merge, ssd_tail
 
 MedSSD = SS2D_with_SSD
 
@@ -75,11 +75,11 @@ class CrossMamba(nn.Module):
             raise RuntimeError("CrossMamba: seq_idx / cu_seqlens are never passed by the reference's models and are not built")
 
         def one(u, u_param):
-            zx = self.skip_in_proj(u)
+            zx = proj(self.skip_in_proj, u)
             d_mlp = (zx.shape[-1] - self.d_ssm) // 2
             z0, x0, z = torch.split(zx, [d_mlp, d_mlp, self.d_ssm], dim=-1)
-            xs = ssd_dwconv_silu(self.xs_conv2d, self.xs_in_proj(u), self.d_conv)                 # (B,H,W,d_ssm)
-            bcd = ssd_dwconv_silu(self.BCdts_conv2d, self.BCdts_in_proj(u_param), self.d_conv)    # (B,H,W,2GN+nheads)
+            xs = ssd_dwconv_silu(self.xs_conv2d, proj(self.xs_in_proj, u), self.d_conv)                 # (B,H,W,d_ssm)
+            bcd = ssd_dwconv_silu(self.BCdts_conv2d, proj(self.BCdts_in_proj, u_param), self.d_conv)    # (B,H,W,2GN+nheads)
             return ssd_tail(self, ssd_scan_merge(self, torch.cat([xs, bcd], dim=-1)), z, z0, x0, d_mlp)
 
         return one(u1, u2_cat_u1), one(u2, u1_cat_u2)

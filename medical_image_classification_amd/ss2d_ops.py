@@ -190,7 +190,7 @@ def linear_splitk(x, weight, out_fp32=False):
         with torch.autocast(device_type="cuda", enabled=False):
             return linear_mfma(x, weight, out_fp32)
     if (_MFMA_GEMM and _F32_GEMM and x.is_cuda and not torch.is_autocast_enabled() and x.dtype == torch.float32
-            and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0):
+            and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0):     # rows of x, dy and W^T: multiples of 16 bytes
         from .gemm_ops import linear_f32           # fp32 runs (the reference's precision): exact-fp32 MFMA kernel, no library GEMM
         return linear_f32(x, weight)
     if x.is_cuda and (x.numel() // x.shape[-1] >= 8192 or (torch.is_autocast_enabled() and x.requires_grad)):
