@@ -386,10 +386,10 @@ int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, i
 //   The workgroup's partial block goes to a workspace row; ms_conv3x3_wgrad sums the rows into the fp32 (Co, Ci, 3, 3) gradient.
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
 
-namespace {
-constexpr int kGC = 48;                          // channels per block (both sides)
-constexpr int kGP = kGC + 8;                     // LDS pixel pitch (bf16)
-}
+// GC = channels per block on both sides: 48 (MedMamba-T's 48 / 96 / 192 / 384), or 64 where that divides both channel counts and 48 does
+// not (MedMamba-B's 64 / 128 / 256 / 512: 48-channel blocks covered 64 channels with 2 x 2 blocks of which 44 % was real work -- the
+// weight gradients were 5.1 of that configuration's 74 ms); 4 co tiles x 9 taps x 4 ci tiles = 36 product columns, 9 per wave.
+constexpr int wgrad_gc(int Ci, int Co) { return (Ci % 64 == 0 && Co % 64 == 0 && (Ci % 48 != 0 || Co % 48 != 0)) ? 64 : 48; }
 
 __device__ __forceinline__ bf16x4 tr_frag(const unsigned short *s_pix0, int pitch, int lane) {
     // fragment of 16 channels (starting at s_pix0's channel) x 16 pixels (rows of the [pixel][channel] image starting at s_pix0):
@@ -399,19 +399,24 @@ __device__ __forceinline__ bf16x4 tr_frag(const unsigned short *s_pix0, int pitc
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(s_pix0 + (4 * fq + (fr >> 2)) * pitch + 4 * (fr & 3)));
 }
 
-__global__ void __launch_bounds__(256)
+// (64-channel blocks: 36 accumulator tiles per wave = 300 registers, one workgroup per CU; capped at 256 registers it spills and
+// measured 157 / 129 / 124 / 133 us against 126 / 120 / 121 / 133 at MedMamba-B's four stages, bs 32 512 x 512)
+template <int kGC>
+__global__ void __launch_bounds__(256, kGC == 64 ? 1 : 2)
 conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, float *__restrict__ part,
                      int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img, int n_tiles, int nci) {
-    __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kGP];      // x halo tile, 48 input channels
-    __shared__ __attribute__((aligned(16))) unsigned short sG[kTH * kTW * kGP];      // dy tile, 48 output channels
+    constexpr int kGP = kGC + 8;                     // LDS pixel pitch (bf16)
+    constexpr int NT = kGC / 16, kCols = 9 * NT;     // channel tiles per side; product columns (tap, ci tile)
+    __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kGP];      // x halo tile, kGC input channels
+    __shared__ __attribute__((aligned(16))) unsigned short sG[kTH * kTW * kGP];      // dy tile, kGC output channels
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cob = blockIdx.y / nci, cib = blockIdx.y % nci;
     const int co0 = cob * kGC, ci0 = cib * kGC;
-    // this wave's product columns: col = tap * 3 + ci tile, col % 4 == wv
-    constexpr int kMaxCols = 7;
-    f32x4 acc[3][kMaxCols];
+    // this wave's product columns: col = tap * NT + ci tile, col % 4 == wv
+    constexpr int kMaxCols = (kCols + 3) / 4;
+    f32x4 acc[NT][kMaxCols];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int j = 0; j < kMaxCols; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -457,32 +462,32 @@ conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short 
         if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
 #pragma unroll 2
         for (int r = 0; r < kTH; ++r) {
-            bf16x4 ga[3];
+            bf16x4 ga[NT];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) ga[a] = tr_frag(sG + (r * kTW) * kGP + a * 16, kGP, lane);
+            for (int a = 0; a < NT; ++a) ga[a] = tr_frag(sG + (r * kTW) * kGP + a * 16, kGP, lane);
 #pragma unroll
             for (int j = 0; j < kMaxCols; ++j) {
                 const int col = wv + 4 * j;                       // compile-time j, wave-uniform col
-                if (col < 27) {
-                    const int tap = col / 3, ct = col - tap * 3;
+                if (col < kCols) {
+                    const int tap = col / NT, ct = col - tap * NT;
                     const int dyy = tap / 3, dxx = tap - dyy * 3;
                     const bf16x4 xb = tr_frag(sX + ((r + dyy) * kHW + dxx) * kGP + ct * 16, kGP, lane);
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[a], xb, acc[a][j], 0, 0, 0);
+                    for (int a = 0; a < NT; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[a], xb, acc[a][j], 0, 0, 0);
                 }
             }
         }
     }
-    // D[co][ci]: lane (ci = fr) holds co = 4 fq + r.  Partial block layout: [co (48)][tap (9)][ci (48)] fp32 per (blockIdx.x, blockIdx.y)
+    // D[co][ci]: lane (ci = fr) holds co = 4 fq + r.  Partial block layout: [co (kGC)][tap (9)][ci (kGC)] fp32 per (blockIdx.x, blockIdx.y)
     const int fr = lane & 15, fq = lane >> 4;
     float *pb = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (kGC * 9 * kGC);
 #pragma unroll
     for (int j = 0; j < kMaxCols; ++j) {
         const int col = wv + 4 * j;
-        if (col < 27) {
-            const int tap = col / 3, ct = col - tap * 3;
+        if (col < kCols) {
+            const int tap = col / NT, ct = col - tap * NT;
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
                     pb[((a * 16 + 4 * fq + rr) * 9 + tap) * kGC + ct * 16 + fr] = acc[a][j][rr];
@@ -496,6 +501,7 @@ conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short 
 // version walked dW's (co, ci, tap) order with one thread per element: 192-byte strides between neighbouring lanes and 81
 // blocks for the whole chip at stage 0 -- 34 us for 42 MB.
 constexpr int kFinCols = 16, kFinSlices = 16;
+template <int kGC>
 __global__ void __launch_bounds__(kFinCols * kFinSlices)
 conv3x3_wgrad_finalize_kernel(const float *__restrict__ part, float *__restrict__ dW, int Ci, int Co, int nci, int nblk, int nworkers) {
     __shared__ float4 red[kFinSlices][kFinCols];
@@ -540,6 +546,7 @@ static int wgrad_workers(int n_tiles, int nblk) {
 int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co) {
     if (batch <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
     const int n_tiles = batch * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+    const int kGC = wgrad_gc(Ci, Co);
     const int nblk = ((Co + kGC - 1) / kGC) * ((Ci + kGC - 1) / kGC);
     return (int64_t)wgrad_workers(n_tiles, nblk) * nblk * (kGC * 9 * kGC);
 }
@@ -551,14 +558,18 @@ int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scra
     if (scratch_floats < conv3x3_wgrad_scratch_floats(batch, H, W, Ci, Co)) return MS_ERR_SHAPE;
     const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH;
     const int tiles_per_img = tiles_w * tiles_h, n_tiles = batch * tiles_per_img;
-    const int nco = (Co + kGC - 1) / kGC, nci = (Ci + kGC - 1) / kGC, nblk = nco * nci;
+    const int gc = wgrad_gc(Ci, Co);
+    const int nco = (Co + gc - 1) / gc, nci = (Ci + gc - 1) / gc, nblk = nco * nci;
     const int wk = wgrad_workers(n_tiles, nblk);
     using bf = unsigned short;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)wk, (unsigned)nblk), dim3(256), 0, s, (const bf *)x, (const bf *)dy, scratch, H, W,
-                       Ci, Co, tiles_w, tiles_per_img, n_tiles, nci);
-    const int64_t nq = (int64_t)nblk * (kGC * 9 * kGC / 4);
-    hipLaunchKernelGGL(conv3x3_wgrad_finalize_kernel, dim3((unsigned)((nq + kFinCols - 1) / kFinCols)), dim3(kFinCols * kFinSlices), 0, s, scratch, dW,
-                       Ci, Co, nci, nblk, wk);
+    const int64_t nq = (int64_t)nblk * (gc * 9 * gc / 4);
+#define MS_WGRAD(GCv)                                                                                                                        \
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<GCv>), dim3((unsigned)wk, (unsigned)nblk), dim3(256), 0, s, (const bf *)x, (const bf *)dy, scratch, H, W, \
+                       Ci, Co, tiles_w, tiles_per_img, n_tiles, nci);                                                                          \
+    hipLaunchKernelGGL((conv3x3_wgrad_finalize_kernel<GCv>), dim3((unsigned)((nq + kFinCols - 1) / kFinCols)), dim3(kFinCols * kFinSlices), 0, s,    \
+                       scratch, dW, Ci, Co, nci, nblk, wk)
+    if (gc == 64) { MS_WGRAD(64); } else { MS_WGRAD(48); }
+#undef MS_WGRAD
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

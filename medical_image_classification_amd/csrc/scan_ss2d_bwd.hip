@@ -233,7 +233,11 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         if (ch > 0) fill_tab(ch - 1);
         // ONE barrier per chunk: (i) this chunk's tiles are staged, (ii) every wave has finished the sweeps of chunk ch + 1, whose
         // dB / dC tiles (other parity) are combined below, (iii) the position table of chunk ch - 1 is written
+#ifdef MS_ABL_NOBAR
+        wave_sync();          // timing only: the workgroup's waves are NOT kept together (results are wrong)
+#else
         __syncthreads();
+#endif
 #ifdef MS_ABL_NOGLD
         if (ch > 0 && ch == n_chunks + 5) prefetch(ch - 1);
 #else
