@@ -484,6 +484,17 @@ int ms_conv3x3_bn_nhwc_bf16(const void *x, const void *w, void *y, int batch, in
  * x (npix, C) bf16 -> y (npix, C) bf16; also writes save_mean / save_rstd and updates the running statistics. */
 int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream);
 
+/* ---- both backward products of a token projection from one pass over its operands (ABI v9) ---------------------------------------------
+ * The autograd of `y = x W^T` (in_proj / x_proj / out_proj, MedMamba.py:284,326,397,469,480) for huge token counts and small widths:
+ *   dx (M, K) = dy (M, N) W (N, K)   written (fp32 or bf16, row stride ld_dx);   dW (N, K) fp32 contiguous += dy^T x   (ZERO-FILLED by the
+ * caller; fp32 atomics).  dy, x: fp32 or bf16 rows (strides ld_dy, ld_x: whole 16-byte pieces, 16-byte aligned bases); W: (N, K)
+ * contiguous, fp32 or bf16.  bf16 MFMA with fp32 accumulation -- the arithmetic of two ms_gemm_bf16 calls -- but dy and x are read
+ * once.  ms_linear_bwd_ok(N, K) tells whether the pair of widths is built (K a multiple of 16; see csrc/linear_bwd.hip);
+ * otherwise MS_ERR_UNSUPPORTED and the caller uses the two-launch form. */
+int ms_linear_bwd_ok(int N, int K);
+int ms_linear_bwd_bf16(const void *dy, int dy_is_f32, int64_t ld_dy, const void *x, int x_is_f32, int64_t ld_x, const void *w, int w_is_f32,
+                       void *dx, int dx_is_bf16, int64_t ld_dx, float *dW, int M, int N, int K, void *stream);
+
 /* Diagnostic: force the workgroup tile of ms_gemm_bf16 (rows 64 / 128, columns 64 / 128 / 192; 0 = the built-in heuristic). */
 int ms_debug_gemm_tile(int block_rows, int block_cols);
 

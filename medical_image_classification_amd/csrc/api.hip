@@ -43,6 +43,9 @@ int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int 
 int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
                              const MsBnFold *bn_out, hipStream_t s);
 int bn_apply_sums_dispatch(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, hipStream_t s);
+int linear_bwd_ok(int N, int K);
+int linear_bwd_dispatch(const void *dy, int dy_f32, int64_t ld_dy, const void *x, int x_f32, int64_t ld_x, const void *w, int w_f32, void *dx,
+                        int dx_bf16, int64_t ld_dx, float *dW, int M, int N, int K, hipStream_t s);
 int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W,
                            int Ci, int Co, hipStream_t s);
 int64_t conv3x3_wgrad_scratch_floats(int batch, int H, int W, int Ci, int Co);
@@ -148,6 +151,13 @@ int ms_conv3x3_bn_nhwc_bf16(const void *x, const void *w, void *y, int batch, in
 
 int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream) {
     return ms::bn_apply_sums_dispatch(x, bn, relu, y, npix, C, (hipStream_t)stream);
+}
+
+int ms_linear_bwd_ok(int N, int K) { return ms::linear_bwd_ok(N, K); }
+
+int ms_linear_bwd_bf16(const void *dy, int dy_is_f32, int64_t ld_dy, const void *x, int x_is_f32, int64_t ld_x, const void *w, int w_is_f32,
+                       void *dx, int dx_is_bf16, int64_t ld_dx, float *dW, int M, int N, int K, void *stream) {
+    return ms::linear_bwd_dispatch(dy, dy_is_f32, ld_dy, x, x_is_f32, ld_x, w, w_is_f32, dx, dx_is_bf16, ld_dx, dW, M, N, K, (hipStream_t)stream);
 }
 
 int ms_conv3x3_wgrad(const void *x, const void *dy, float *dW, float *scratch, int64_t scratch_floats, int batch, int H, int W, int Ci,

@@ -8,6 +8,8 @@ MFMA kernel `ms_gemm_bf16` (csrc/gemm.hip; C ABI in include/medscan.h): bf16 mat
 This is the autocast-bf16 path (what the reference's nn.Linear / einsum do under `torch.autocast(bfloat16)`); fp32 runs keep
 the stock fp32 GEMMs.  CUDA (HIP) tensors only -- no CPU fallback.
 """
+import os
+
 import torch
 
 from . import _lib, arena, shadow
@@ -110,6 +112,47 @@ def gemm(a, b, a_trans=False, b_trans=False, out=None, out_dtype=torch.float32, 
     return out
 
 
+_FUSED_BWD = os.environ.get("MEDSCAN_LINEAR_BWD_FUSED", "1") == "1"
+_FUSED_BWD_MIN_ROWS = int(os.environ.get("MEDSCAN_LINEAR_BWD_MIN_ROWS", "16384"))
+_FUSED_BWD_MIN_ROW_BYTES = int(os.environ.get("MEDSCAN_LINEAR_BWD_MIN_ROW_BYTES", "512"))
+
+
+def linear_bwd_fused_ok(dy, x, w):
+    """Both backward products of y = x W^T from one pass (ms_linear_bwd_bf16): 2-D operands the kernel reads in place, a width pair it is
+    built for, and enough token rows that streaming dy / x once is what matters (the early stages)."""
+    if not (_FUSED_BWD and dy.is_cuda and dy.dim() == 2 and x.dim() == 2 and w.dim() == 2 and w.is_contiguous() and dy.shape[0] >= _FUSED_BWD_MIN_ROWS):
+        return False
+    N, K = w.shape
+    if dy.shape[1] != N or x.shape[1] != K or x.shape[0] != dy.shape[0]:
+        return False
+    for t in (dy, x):
+        g = 4 if t.dtype == torch.float32 else 8
+        if t.dtype not in (torch.float32, torch.bfloat16) or t.stride(1) != 1 or t.stride(0) % g != 0 or t.data_ptr() % 16 != 0:
+            return False
+    if w.dtype not in (torch.float32, torch.bfloat16) or w.data_ptr() % 16 != 0:
+        return False
+    if N % (4 if dy.dtype == torch.float32 else 8) != 0:
+        return False
+    # rows of at least 512 bytes of dy + x: below that (in_proj / out_proj of MedMamba-T's stage 0: 480 / 384 B) the two-launch form, whose
+    # operands then mostly come from the caches, measured faster in situ (50 / 41 us against 57 / 46); x_proj (944 B): 166 -> 101 us
+    if N * dy.element_size() + K * x.element_size() < _FUSED_BWD_MIN_ROW_BYTES:
+        return False
+    return bool(_lib.lib().ms_linear_bwd_ok(N, K))
+
+
+def linear_bwd_fused(dy, x, w, dx_dtype=torch.float32):
+    """(dx, dW) = (dy @ W, dy^T @ x): dx (M, K) in `dx_dtype` (fp32 / bf16), dW (N, K) fp32.  See linear_bwd_fused_ok."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dx = torch.empty((M, K), device=dy.device, dtype=dx_dtype)
+    dw = arena.zeros((N, K), dy.device)
+    with _lib.on_device(dy.device):
+        _lib.check(_lib.lib().ms_linear_bwd_bf16(dy.data_ptr(), _is_f32(dy), dy.stride(0), x.data_ptr(), _is_f32(x), x.stride(0), w.data_ptr(),
+                                                 _is_f32(w), dx.data_ptr(), int(dx_dtype == torch.bfloat16), dx.stride(0), dw.data_ptr(), M, N, K,
+                                                 _lib.current_stream_ptr(dy.device)), "ms_linear_bwd_bf16")
+    return dx, dw
+
+
 def _rows(t):
     """(.., K) -> (M, K) view usable by the kernel (unit inner stride, uniform row stride) or a contiguous copy."""
     t2 = t.reshape(-1, t.shape[-1])
@@ -143,6 +186,9 @@ class _LinearMFMA(torch.autograd.Function):
         N, K = w.shape
         dym = _rows(dy)
         dx = None
+        if ctx.needs_input_grad[0] and linear_bwd_fused_ok(dym, xm, w):
+            dx, dw = linear_bwd_fused(dym, xm, w, torch.bfloat16 if ctx.xdtype == torch.bfloat16 else torch.float32)
+            return dx.view(ctx.xshape), dw.to(ctx.wdtype), None
         if ctx.needs_input_grad[0]:
             dx = gemm(dym, w, b_trans=True, out_dtype=torch.bfloat16 if ctx.xdtype == torch.bfloat16 else torch.float32)
             dx = dx.view(ctx.xshape)

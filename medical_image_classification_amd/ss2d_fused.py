@@ -20,7 +20,7 @@ import torch
 
 from . import _lib, arena, shadow
 from ._lib import MsScanBwdParams, MsScanParams
-from .gemm_ops import gemm, gemm_f32, weight_grad, weight_grad_f32
+from .gemm_ops import gemm, gemm_f32, linear_bwd_fused, linear_bwd_fused_ok, weight_grad, weight_grad_f32
 from .selective_scan_interface import TIMER, algorithmic_bytes
 from .ss2d_ops import _F32_GEMM, _MFMA_GEMM, _MFMA_MIN_ROWS
 
@@ -464,7 +464,9 @@ class _SS2DInner(torch.autograd.Function):
             dwdt = _dtproj_bwd(ddelta, proj, wdt, dproj, B, L, D, R, C)
             # x_proj backward: input gradient in fp32 straight out of the GEMM, split-K weight gradient
             dpm = dproj.view(M, 4 * C)
-            if ctx.mfma:
+            if ctx.mfma and linear_bwd_fused_ok(dpm, xc.view(M, D), wx):
+                dxe, dwx = linear_bwd_fused(dpm, xc.view(M, D), wx)    # both products from one pass over dproj and xc (early stages)
+            elif ctx.mfma:
                 dxe = gemm(dpm, wx, b_trans=True)                      # fp32 dproj read in place, fp32 result
                 dwx = weight_grad(dpm, xc.view(M, D))
             elif ctx.f32mm:

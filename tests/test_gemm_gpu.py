@@ -231,3 +231,60 @@ def test_f32_linear_autograd_matches_f_linear_and_fp32_model_uses_it(monkeypatch
         out = blk(xi)
         out.sum().backward()
     assert not a.seen, a.seen
+
+
+# ---- both backward products of a projection from one pass (csrc/linear_bwd.hip, ABI v9) ----------------------------------------
+@pytest.mark.parametrize("M,N,K,dy_dt,x_dt,dx_dt", [
+    (20000, 140, 96, torch.float32, torch.float32, torch.float32),        # x_proj, MedMamba-T stage 0 (ragged N: 4 (R + 2 * 16) = 140)
+    (17000, 192, 48, torch.bfloat16, torch.bfloat16, torch.bfloat16),     # in_proj
+    (16500, 48, 96, torch.float32, torch.bfloat16, torch.bfloat16),       # out_proj (N padded to 64 inside the kernel)
+    (16400, 144, 128, torch.float32, torch.float32, torch.float32),       # MedMamba-B stage 0
+    (16384, 256, 64, torch.bfloat16, torch.bfloat16, torch.float32),
+    (16390, 64, 128, torch.bfloat16, torch.float32, torch.bfloat16),
+    (70, 140, 96, torch.float32, torch.float32, torch.float32),           # one partial slab (rows threshold lowered below)
+])
+def test_linear_backward_both_products_from_one_pass(M, N, K, dy_dt, x_dt, dx_dt, monkeypatch):
+    """ms_linear_bwd_bf16 vs float64 products of the SAME bf16-rounded operands (what the MFMA multiplies): dx to 1e-5 (+ the bf16 store's
+    2^-8 when it is written in bf16), dW to 2e-5 of its max-norm (fp32 accumulation over M tokens, atomics in any order); and vs the
+    two-launch form (ms_gemm_bf16 twice), which must agree to the same bounds."""
+    from medical_image_classification_amd import gemm_ops
+    monkeypatch.setattr(gemm_ops, "_FUSED_BWD_MIN_ROWS", 1)
+    monkeypatch.setattr(gemm_ops, "_FUSED_BWD_MIN_ROW_BYTES", 0)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    dy = (torch.randn(M, N, device=dev, generator=g) * 0.5).to(dy_dt)
+    x = (torch.randn(M, K, device=dev, generator=g) + 0.3).to(x_dt)
+    w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5)
+    wb = w.to(torch.bfloat16)
+    for wt in (w, wb):
+        assert gemm_ops.linear_bwd_fused_ok(dy, x, wt)
+        dx, dw = gemm_ops.linear_bwd_fused(dy, x, wt, dx_dt)
+        torch.cuda.synchronize()
+        r = lambda t: t.to(torch.bfloat16).double()
+        dx_ref, dw_ref = r(dy) @ r(wt), r(dy).t() @ r(x)
+        tol_dx = 1e-5 + (2 ** -8 if dx_dt == torch.bfloat16 else 0.0)
+        assert float((dx.double() - dx_ref).abs().max()) <= tol_dx * float(dx_ref.abs().max()), "dx"
+        assert float((dw.double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max()), "dW"
+        assert dw.dtype == torch.float32 and dw.shape == (N, K) and dx.dtype == dx_dt
+    dx2 = gemm_ops.gemm(dy, wb, b_trans=True, out_dtype=dx_dt)
+    dw2 = gemm_ops.weight_grad(dy, x)
+    assert float((dx.double() - dx2.double()).abs().max()) <= 2 * tol_dx * float(dx_ref.abs().max())
+    assert float((dw.double() - dw2.double()).abs().max()) <= 4e-5 * float(dw_ref.abs().max())
+
+
+def test_linear_backward_fused_gate_and_errors():
+    from medical_image_classification_amd import _lib, gemm_ops
+    lib = _lib.lib()
+    assert lib.ms_linear_bwd_ok(140, 96) == 1 and lib.ms_linear_bwd_ok(192, 48) == 1 and lib.ms_linear_bwd_ok(48, 96) == 1
+    assert lib.ms_linear_bwd_ok(384, 96) == 0 and lib.ms_linear_bwd_ok(140, 100) == 0 and lib.ms_linear_bwd_ok(0, 96) == 0
+    dev = torch.device("cuda:0")
+    dy, x, w = torch.zeros(20000, 140, device=dev), torch.zeros(20000, 96, device=dev), torch.zeros(140, 96, device=dev)
+    assert gemm_ops.linear_bwd_fused_ok(dy, x, w)
+    assert not gemm_ops.linear_bwd_fused_ok(dy[:1000], x[:1000], w)                  # few rows: the two-launch form
+    assert not gemm_ops.linear_bwd_fused_ok(torch.zeros(20000, 48, device=dev), x.to(torch.bfloat16), torch.zeros(48, 96, device=dev))   # short rows (384 B): likewise
+    assert not gemm_ops.linear_bwd_fused_ok(dy, x, torch.zeros(384, 96, device=dev))
+    assert not gemm_ops.linear_bwd_fused_ok(dy[:, 1:], x, w[1:])                     # misaligned rows
+    st = _lib.current_stream_ptr(dev)
+    assert lib.ms_linear_bwd_bf16(None, 1, 140, x.data_ptr(), 1, 96, w.data_ptr(), 1, x.data_ptr(), 0, 96, w.data_ptr(), 20000, 140, 96, st) == -1
+    assert lib.ms_linear_bwd_bf16(dy.data_ptr(), 1, 140, x.data_ptr(), 1, 96, w.data_ptr(), 1, x.data_ptr(), 0, 96, w.data_ptr(), 20000, 384, 96, st) == -6
+    assert lib.ms_linear_bwd_bf16(dy.data_ptr(), 1, 141, x.data_ptr(), 1, 96, w.data_ptr(), 1, x.data_ptr(), 0, 96, w.data_ptr(), 20000, 140, 96, st) == -4

@@ -9,7 +9,7 @@ SRC=$ROOT/medical_image_classification_amd/csrc
 OUT=$ROOT/build/variants/$NAME
 mkdir -p $OUT
 OBJS=""
-for f in api scan_fwd scan_bwd scan_bwd_ssd scan_ss2d scan_ss2d_bwd gemm gemm_f32 cross dwconv dwconv_nhwc ln_gate block_tail ln dtproj bn_relu ssd_carry ssd_chunk rms_gate cast conv3x3 adam; do
+for f in api scan_fwd scan_bwd scan_bwd_ssd scan_ss2d scan_ss2d_bwd gemm gemm_f32 linear_bwd cross dwconv dwconv_nhwc ln_gate block_tail ln dtproj bn_relu ssd_carry ssd_chunk rms_gate cast conv3x3 adam; do
   if [[ " $FILES " == *" $f.hip "* ]]; then
     FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-gpu-rdc -Wno-unused-function -fno-slp-vectorize"
     [[ $f == scan_bwd || $f == scan_ss2d_bwd ]] && FL="$FL -mllvm -amdgpu-sched-strategy=${SCHED:-iterative-ilp}"
