@@ -41,9 +41,14 @@ linear_bwd_kernel(const void *__restrict__ dy, int dy_f32, int64_t ld_dy, const 
     constexpr int NP = NT * 16, KP = KT * 16;
     constexpr int PDY = NP + 8, PX = KP + 8, PW = KP + 8;                 // LDS pitches (bf16 elements; rows stay 16-byte aligned)
     constexpr int kStage = (kSlab * PDY + kSlab * PX + NP * PW) * 2, kOut = NP * KP * 4;
-    constexpr int kBytes = kStage > kOut ? kStage : kOut;
+    constexpr int kMain = kStage > kOut ? kStage : kOut;
+    // + the slab's dx tile [64][KP] fp32: the MFMA layout gives a lane 16 bytes of one row -- a wave-level store of it touches sixteen
+    // 64-byte fragments 4 K bytes apart (the counters showed the waves stalled on ISSUE for half of the kernel); through LDS every
+    // wave-level store is 1 KB of consecutive addresses
+    constexpr int kBytes = kMain + kSlab * KP * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes];
     unsigned short *sDY = reinterpret_cast<unsigned short *>(smem), *sX = sDY + kSlab * PDY, *sW = sX + kSlab * PX;
+    float *sDX = reinterpret_cast<float *>(smem + kMain);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
 
@@ -138,22 +143,10 @@ linear_bwd_kernel(const void *__restrict__ dy, int dy_f32, int64_t ld_dy, const 
                     accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa, accx[b], 0, 0, 0);
                 }
             }
-            const int m = slab * kSlab + wv * 16 + fr;     // acc[r] = dx[m][16 b + 4 fq + r]
-            if (m < M) {
+            // acc[r] = dx[16 wv + fr][16 b + 4 fq + r] -> sDX (read back in row order after the weight-gradient steps below)
 #pragma unroll
-                for (int b = 0; b < KT; ++b) {
-                    const f32x4 v = accx[b];
-                    const int k = b * 16 + fq * 4;
-                    if (dx_bf16) {
-                        uint2 pk;
-                        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                        *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(dx) + (int64_t)m * ld_dx + k) = pk;
-                    } else {
-                        *reinterpret_cast<float4 *>(static_cast<float *>(dx) + (int64_t)m * ld_dx + k) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-            }
+            for (int b = 0; b < KT; ++b)
+                *reinterpret_cast<float4 *>(sDX + (wv * 16 + fr) * KP + b * 16 + fq * 4) = make_float4(accx[b][0], accx[b][1], accx[b][2], accx[b][3]);
         }
         // ---- dW += dy^T x over the slab's 64 tokens (two 32-deep steps) ----
 #pragma unroll
@@ -169,6 +162,27 @@ linear_bwd_kernel(const void *__restrict__ dy, int dy_f32, int64_t ld_dy, const 
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
                         if (wn + 2 * a < NT) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[a], accw[a][b], 0, 0, 0);
+                }
+            }
+        }
+        // ---- the slab's dx rows, 16 bytes per lane in row order (the barrier at the top of the next trip orders the next writes) ----
+        __syncthreads();
+        {
+            const int m0 = slab * kSlab;
+            constexpr int kQ = kSlab * KP / 4;                   // float4 pieces of the tile
+#pragma unroll
+            for (int i = 0; i < (kQ + 255) / 256; ++i) {
+                const int q = tid + 256 * i, row = q / (KP / 4), c4 = q % (KP / 4);
+                if (q < kQ && m0 + row < M) {
+                    const float4 v = *reinterpret_cast<const float4 *>(sDX + row * KP + c4 * 4);
+                    if (dx_bf16) {
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                        *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(dx) + (int64_t)(m0 + row) * ld_dx + c4 * 4) = pk;
+                    } else {
+                        *reinterpret_cast<float4 *>(static_cast<float *>(dx) + (int64_t)(m0 + row) * ld_dx + c4 * 4) = v;
+                    }
                 }
             }
         }
