@@ -19,6 +19,8 @@ template <int VPT, int RP>
 __global__ void __launch_bounds__(256)
 dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ delta,
                   int64_t npix, int D, int R, int C, int ncb) {
+    // (wv is deliberately NOT made wave-uniform here: with scalar loads the three dts values of a pixel arrive as three s_load_dword
+    // behind one lgkmcnt wait each -- 187 us against 104 with broadcast vector loads)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k = blockIdx.y / ncb, cb = blockIdx.y % ncb;
     const int dbase = cb * 64 * VPT;
@@ -45,28 +47,42 @@ dtproj_fwd_kernel(const float *__restrict__ proj, const float *__restrict__ W, c
 #pragma unroll
     for (int j = 0; j < VPT; ++j) bv[j] = (bias && dbase + lane + 64 * j < D) ? bias[(int64_t)k * D + dbase + lane + 64 * j] : 0.0f;
     float *dk = delta + (int64_t)k * npix * D;
-    constexpr int PB = 8;                       // pixels per wave (one trip: nothing to accumulate, the hardware overlaps waves)
-    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB;
+    // 8 pixels per trip; a wave makes several trips (grid sized for ~MS_DT_FWD_TRIPS of them) so that its prologue -- the weight and
+    // bias loads above -- is paid once per ~64 pixels instead of once per 8, with the next trip's dts rows requested before this trip's
+    // stores (one-trip waves: 110 us for 308 MB of stores at stage 0 of MedMamba-T)
+    constexpr int PB = 8;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PB;
+    int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PB;
     if (p0 >= npix) return;
-    float t[PB][RP];
+    float t[PB][RP], tn[PB][RP];
+    auto load = [&](int64_t pb, float (&tt)[PB][RP]) {
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-        const int64_t p = min(p0 + q, npix - 1);
-        const float *row = proj + (p * 4 + k) * C;                // wave-uniform address
+        for (int q = 0; q < PB; ++q) {
+            const int64_t p = min(pb + q, npix - 1);
+            const float *row = proj + (p * 4 + k) * C;            // wave-uniform address
 #pragma unroll
-        for (int r = 0; r < RP; ++r) t[q][r] = r < R ? row[r] : 0.0f;
-    }
-    float *o = dk + p0 * D + dbase + lane;
+            for (int r = 0; r < RP; ++r) tt[q][r] = r < R ? row[r] : 0.0f;
+        }
+    };
+    load(p0, tn);
+    for (; p0 < npix; p0 += stride) {
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-        if (p0 + q < npix) {
+        for (int q = 0; q < PB; ++q)
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                float a = 0.0f;
+            for (int r = 0; r < RP; ++r) t[q][r] = tn[q][r];
+        if (p0 + stride < npix) load(p0 + stride, tn);
+        float *o = dk + p0 * D + dbase + lane;
 #pragma unroll
-                for (int r = 0; r < RP; ++r) a = fmaf(t[q][r], w[j][r], a);
-                if (bias) a = softplus_ref(a + bv[j]);
-                if (dbase + lane + 64 * j < D) o[q * D + 64 * j] = a;
+        for (int q = 0; q < PB; ++q) {
+            if (p0 + q < npix) {
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) a = fmaf(t[q][r], w[j][r], a);
+                    if (bias) a = softplus_ref(a + bv[j]);
+                    if (dbase + lane + 64 * j < D) o[q * D + 64 * j] = a;
+                }
             }
         }
     }
@@ -78,7 +94,7 @@ dtproj_bwd_kernel(const float *__restrict__ ddelta, const float *__restrict__ pr
                   float *__restrict__ dproj, float *__restrict__ dW, int64_t npix, int D, int R, int C, int ncb) {
     __shared__ __attribute__((aligned(16))) float sT[4][RP * 64];        // per wave: partial ddts [r][lane]
     __shared__ float sW[3][VPT * 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the dts rows come through scalar loads
     const int k = blockIdx.y / ncb, cb = blockIdx.y % ncb;
     const int dbase = cb * 64 * VPT;
     float w[VPT][RP], acc[VPT][RP];
@@ -94,7 +110,10 @@ dtproj_bwd_kernel(const float *__restrict__ ddelta, const float *__restrict__ pr
     // ownership for the cross-lane sum: lanes [rr*LPR, (rr+1)*LPR) sum row rr of the tile, RP values each
     constexpr int LPR = 64 / RP;                                  // lanes per r (RP = 4, 8, 16, 32 -> 16, 8, 4, 2)
     const int rr = lane / LPR, seg = lane % LPR;
-    constexpr int PB = 2;
+#ifndef MS_DT_BWD_PB
+#define MS_DT_BWD_PB 4
+#endif
+    constexpr int PB = MS_DT_BWD_PB;
     float g[PB][VPT], t[PB][RP], gn[PB][VPT], tn[PB][RP];
     auto load = [&](int64_t p0, float (&gg)[PB][VPT], float (&tt)[PB][RP]) {
 #pragma unroll
@@ -435,7 +454,9 @@ static int launch_dt(bool bwd, const float *a, const float *proj, const float *W
     const int ncb = (D + 64 * vpt - 1) / (64 * vpt);
     // forward: one trip per wave (8 pixels).  backward: persistent waves (dWdt accumulators), at least 16 trips each so the
     // closing LDS-combine + atomics round is amortised, at most kDtMaxBlocksX workgroups per (direction, channel block)
-    int64_t blocks = bwd ? (npix + 2 * 4 * 16 - 1) / (2 * 4 * 16) : (npix + 8 * 4 - 1) / (8 * 4);
+    static const int fwd_trips = [] { const char *e = getenv("MEDSCAN_DT_FWD_TRIPS"); return e ? atoi(e) : 8; }();
+    const int trips = npix >= 32768 ? (fwd_trips < 1 ? 1 : fwd_trips) : 1;      // small maps: one trip per wave (more, shorter waves)
+    int64_t blocks = bwd ? (npix + 2 * 4 * 16 - 1) / (2 * 4 * 16) : (npix + 8 * 4 * trips - 1) / (8 * 4 * trips);
     if (bwd && blocks > kDtMaxBlocksX) blocks = kDtMaxBlocksX;
     const dim3 grid((unsigned)(blocks < 1 ? 1 : blocks), (unsigned)(4 * ncb)), block(256);
 #define MS_DT(V)                                                                                                         \
