@@ -480,6 +480,22 @@ typedef struct MsBnFold {
  *   bn_out : the statistics of y (as stored, bf16-rounded) are accumulated into bn_out->sums. */
 int ms_conv3x3_bn_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
                             const MsBnFold *bn_out, void *stream);
+/* Backward side: the reduce pass of a BatchNorm's backward (dbeta = sum dy', dgamma = sum dy' * xhat, dy' = dy * [relu passed]) in the
+ * epilogue of the 3x3 convolution's INPUT-GRADIENT launch that produces dy -- ms_conv3x3_nhwc_bf16(dy_conv, w', dx) with the sums of dx
+ * against the BatchNorm's pre-normalisation input x_pre ((npix, C) rows, fp32 or bf16, pixel stride x_pre_pixel_stride: a multiple of 4
+ * elements) accumulated into `sums` (MS_BN_REPLICAS x 2 x C floats, ZERO-FILLED by the caller).  ms_bn_bwd_apply_sums_nhwc then writes
+ * dx_bn = gamma * rstd * (dy' - dbeta / n - xhat * dgamma / n) in one pass over (x_pre, dy) and the totals dgamma / dbeta (C each). */
+typedef struct MsBnBwd {
+    const void *x_pre;
+    int x_pre_is_f32;
+    int64_t x_pre_pixel_stride;
+    const float *gamma, *beta, *save_mean, *save_rstd;
+    int relu;
+    float *sums;
+} MsBnBwd;
+int ms_conv3x3_bnbwd_nhwc_bf16(const void *dy, const void *w, void *dx, int batch, int H, int W, int Ci, int Co, const MsBnBwd *red, void *stream);
+int ms_bn_bwd_apply_sums_nhwc(const MsBnBwd *bn, const void *dy, void *dx, int dx_is_bf16, float *dgamma, float *dbeta, int64_t npix, int C,
+                              void *stream);
 /* The consumer for a BatchNorm that is not followed by a 3x3 convolution: y = [relu](bn(x)) from the producer's sums, one pass over
  * x (npix, C) bf16 -> y (npix, C) bf16; also writes save_mean / save_rstd and updates the running statistics. */
 int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream);

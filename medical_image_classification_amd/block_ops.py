@@ -481,80 +481,123 @@ def _bn_fold_desc(sums, gamma, beta, shift, bn, save):
     return d
 
 
+def _bn_bwd_desc(xpre, ps, gamma, beta, save, relu, sums):
+    d = _lib.MsBnBwd()
+    d.x_pre, d.x_pre_is_f32, d.x_pre_pixel_stride = xpre.data_ptr(), int(xpre.dtype == torch.float32), ps
+    d.gamma, d.beta, d.save_mean, d.save_rstd = gamma.data_ptr(), beta.data_ptr(), save[0].data_ptr(), save[1].data_ptr()
+    d.relu, d.sums = int(relu), sums.data_ptr()
+    return d
+
+
 class _ConvBnConvBn(torch.autograd.Function):
-    """x2 = relu(bn2(conv2(relu(bn1(conv1(x0)))))) for training-mode BatchNorms on a bf16 channels_last activation
-    (`conv33conv33conv11[1:7]`, MedMamba.py:518-524) in THREE launches: conv1 accumulates the statistics of its output in its epilogue;
-    conv2 normalises + rectifies conv1's output while it stages its input tiles (writing the normalised activation `x1` as a side
-    output for the backward) and accumulates the statistics of ITS output; one apply pass produces x2.  Was 2 convolutions + 2 x
-    (statistics, finalize, apply).  The backward is the unfused one (BatchNorm backward kernels on the saved pre-BN activations, the
-    convolutions' input / weight gradient kernels on the saved conv inputs).  The conv biases never touch the activations (a constant
-    in front of a mean subtraction): they enter the running means only and get exact zero gradients."""
+    """x2 = relu(bn2(conv2(relu(bn1(conv1(bn0(x))))))) for training-mode BatchNorms on a channels_last activation
+    (`conv33conv33conv11[0:7]`, MedMamba.py:517-524).  Forward: bn0 as statistics / finalize / apply (its input comes from outside), then
+    THREE launches for the rest -- conv1 accumulates the statistics of its output in its epilogue; conv2 normalises + rectifies conv1's
+    output while it stages its input tiles (writing the normalised activation `x1` as a side output for the backward) and accumulates
+    the statistics of ITS output; one apply pass produces x2 (was 2 convolutions + 2 x (statistics, finalize, apply)).
+    Backward: the reduce passes of bn1 and bn0 ride in the epilogues of the input-gradient launches of conv2 and conv1 (`BRED`), their apply
+    passes read the replica rows; bn2 (whose incoming gradient is the 1x1 convolution's) keeps its three launches.
+    The conv biases never touch the activations (a constant in front of a mean subtraction): they enter the running means only and get
+    exact zero gradients."""
 
     @staticmethod
-    def forward(ctx, x0, w1, b1, g1, be1, w2, b2, g2, be2, bn1, bn2):
-        B, C, H, W = x0.shape
+    def forward(ctx, x, g0, be0, w1, b1, g1, be1, w2, b2, g2, be2, bn0, bn1, bn2):
+        B, C, H, W = x.shape
+        npix = B * H * W
         lib = _lib.lib()
+        ps = _nhwc_pixel_stride(x)
         wb1, wb2 = shadow.bf16(w1, conv=True), shadow.bf16(w2, conv=True)
         f32 = lambda t: t.detach().float().contiguous()
-        g1f, be1f, g2f, be2f = f32(g1), f32(be1), f32(g2), f32(be2)
+        g0f, be0f, g1f, be1f, g2f, be2f = f32(g0), f32(be0), f32(g1), f32(be1), f32(g2), f32(be2)
         b1f, b2f = (f32(b1) if b1 is not None else None), (f32(b2) if b2 is not None else None)
         nf = (2 * _lib.BN_REPLICAS + 1) * C
-        sums = torch.zeros(2 * nf, device=x0.device, dtype=torch.float32)
-        save = torch.empty((4, C), device=x0.device, dtype=torch.float32)
-        new = lambda: torch.empty((B, C, H, W), device=x0.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
-        y1, x1, y2, x2 = new(), new(), new(), new()
-        d1 = _bn_fold_desc(sums[:nf], g1f, be1f, b1f, bn1, save[0:2])
-        d2 = _bn_fold_desc(sums[nf:], g2f, be2f, b2f, bn2, save[2:4])
-        st = _stream(x0)
-        with _lib.on_device(x0.device):
+        sums = torch.zeros(2 * nf, device=x.device, dtype=torch.float32)
+        save = torch.empty((6, C), device=x.device, dtype=torch.float32)
+        new = lambda: torch.empty((B, C, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        x0, y1, x1, y2, x2 = new(), new(), new(), new(), new()
+        d1 = _bn_fold_desc(sums[:nf], g1f, be1f, b1f, bn1, save[2:4])
+        d2 = _bn_fold_desc(sums[nf:], g2f, be2f, b2f, bn2, save[4:6])
+        st = _stream(x)
+        with _lib.on_device(x.device):
+            _lib.check(lib.ms_bn_relu_nhwc_fwd(x.data_ptr(), int(x.dtype == torch.bfloat16), ps, None, g0f.data_ptr(), be0f.data_ptr(),
+                                               bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(),
+                                               bn0.num_batches_tracked.data_ptr() if bn0.num_batches_tracked is not None else None,
+                                               float(bn0.momentum), float(bn0.eps), 0, x0.data_ptr(), 1, save[0].data_ptr(), save[1].data_ptr(),
+                                               _bn_scratch(x.device, C).data_ptr(), npix, C, st), "ms_bn_relu_nhwc_fwd")
             _lib.check(lib.ms_conv3x3_bn_nhwc_bf16(x0.data_ptr(), wb1.data_ptr(), y1.data_ptr(), B, H, W, C, C, None, None, ctypes.byref(d1), st),
                        "ms_conv3x3_bn_nhwc_bf16")
             _lib.check(lib.ms_conv3x3_bn_nhwc_bf16(y1.data_ptr(), wb2.data_ptr(), y2.data_ptr(), B, H, W, C, C, ctypes.byref(d1), x1.data_ptr(),
                                                    ctypes.byref(d2), st), "ms_conv3x3_bn_nhwc_bf16")
-            _lib.check(lib.ms_bn_apply_sums_nhwc(y2.data_ptr(), ctypes.byref(d2), 1, x2.data_ptr(), B * H * W, C, st), "ms_bn_apply_sums_nhwc")
-        ctx.save_for_backward(x0, y1, x1, y2, g1f, be1f, g2f, be2f, save)
-        ctx.w1, ctx.w2, ctx.b1, ctx.b2 = w1, w2, b1, b2
-        ctx.dtypes = (g1.dtype, be1.dtype, g2.dtype, be2.dtype)
+            _lib.check(lib.ms_bn_apply_sums_nhwc(y2.data_ptr(), ctypes.byref(d2), 1, x2.data_ptr(), npix, C, st), "ms_bn_apply_sums_nhwc")
+        ctx.save_for_backward(x, x0, y1, x1, y2, g0f, be0f, g1f, be1f, g2f, be2f, save)
+        ctx.w1, ctx.w2, ctx.b1, ctx.b2, ctx.ps = w1, w2, b1, b2, ps
+        ctx.dtypes = (g0.dtype, be0.dtype, g1.dtype, be1.dtype, g2.dtype, be2.dtype)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        x0, y1, x1, y2, g1f, be1f, g2f, be2f, save = ctx.saved_tensors
-        B, C, H, W = x0.shape
-        shadow.invalidate(x0.device)
+        x, x0, y1, x1, y2, g0f, be0f, g1f, be1f, g2f, be2f, save = ctx.saved_tensors
+        B, C, H, W = x.shape
+        npix = B * H * W
+        dev = x.device
+        shadow.invalidate(dev)
         lib = _lib.lib()
         if dx2.dtype not in (torch.float32, torch.bfloat16):
             dx2 = dx2.float()
         dx2 = dx2.contiguous(memory_format=torch.channels_last)
-
-        def bn_bwd(xpre, dy, g, b, sv):
-            dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
-            dgb = torch.empty((2, C), device=dy.device, dtype=torch.float32)
-            with _lib.on_device(dy.device):
-                _lib.check(lib.ms_bn_relu_nhwc_bwd(xpre.data_ptr(), 1, C, dy.data_ptr(), int(dy.dtype == torch.bfloat16), g.data_ptr(), b.data_ptr(),
-                                                   sv[0].data_ptr(), sv[1].data_ptr(), 1, dx.data_ptr(), 1, dgb[0].data_ptr(), dgb[1].data_ptr(),
-                                                   _bn_scratch(dy.device, C).data_ptr(), B * H * W, C, _stream(dy)), "ms_bn_relu_nhwc_bwd")
-            return dx, dgb
-
-        dy2, dgb2 = bn_bwd(y2, dx2, g2f, be2f, save[2:4])
-        dw2 = _conv3x3_wgrad(x1, dy2, ctx.w2.shape) if ctx.needs_input_grad[5] else None
-        dx1 = _conv3x3_direct(dy2, shadow.bf16(ctx.w2, conv="flip", in_backward=True))
-        dy1, dgb1 = bn_bwd(y1, dx1, g1f, be1f, save[0:2])
-        dw1 = _conv3x3_wgrad(x0, dy1, ctx.w1.shape) if ctx.needs_input_grad[1] else None
-        dx0 = _conv3x3_direct(dy1, shadow.bf16(ctx.w1, conv="flip", in_backward=True)) if ctx.needs_input_grad[0] else None
-        t1, t2, t3, t4 = ctx.dtypes
+        new = lambda dt=torch.bfloat16: torch.empty((B, C, H, W), device=dev, dtype=dt, memory_format=torch.channels_last)
+        st = _stream(dx2)
+        # bn2: its incoming gradient comes from the 1x1 convolution -- the three-launch backward
+        dy2, dgb2 = new(), torch.empty((2, C), device=dev, dtype=torch.float32)
+        with _lib.on_device(dev):
+            _lib.check(lib.ms_bn_relu_nhwc_bwd(y2.data_ptr(), 1, C, dx2.data_ptr(), int(dx2.dtype == torch.bfloat16), g2f.data_ptr(), be2f.data_ptr(),
+                                               save[4].data_ptr(), save[5].data_ptr(), 1, dy2.data_ptr(), 1, dgb2[0].data_ptr(), dgb2[1].data_ptr(),
+                                               _bn_scratch(dev, C).data_ptr(), npix, C, st), "ms_bn_relu_nhwc_bwd")
+        dw2 = _conv3x3_wgrad(x1, dy2, ctx.w2.shape) if ctx.needs_input_grad[7] else None
+        bsums = arena.zeros((2, 2 * _lib.BN_REPLICAS * C), dev)
+        dgb = torch.empty((4, C), device=dev, dtype=torch.float32)
+        # conv2's input gradient with bn1's reduce in its epilogue, then bn1's apply from the rows
+        r1 = _bn_bwd_desc(y1, C, g1f, be1f, save[2:4], True, bsums[0])
+        dx1, dy1 = new(), new()
+        wf2, wf1 = shadow.bf16(ctx.w2, conv="flip", in_backward=True), shadow.bf16(ctx.w1, conv="flip", in_backward=True)
+        with _lib.on_device(dev):
+            _lib.check(lib.ms_conv3x3_bnbwd_nhwc_bf16(dy2.data_ptr(), wf2.data_ptr(), dx1.data_ptr(), B, H, W, C, C, ctypes.byref(r1), st),
+                       "ms_conv3x3_bnbwd_nhwc_bf16")
+            _lib.check(lib.ms_bn_bwd_apply_sums_nhwc(ctypes.byref(r1), dx1.data_ptr(), dy1.data_ptr(), 1, dgb[0].data_ptr(), dgb[1].data_ptr(), npix, C,
+                                                     st), "ms_bn_bwd_apply_sums_nhwc")
+        dw1 = _conv3x3_wgrad(x0, dy1, ctx.w1.shape) if ctx.needs_input_grad[3] else None
+        # conv1's input gradient with bn0's reduce (no ReLU; pre-normalisation input = the block's strided left half), then bn0's apply
+        dxin = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            r0 = _bn_bwd_desc(x, ctx.ps, g0f, be0f, save[0:2], False, bsums[1])
+            dx0 = new()
+            dxin = new(x.dtype)                                         # written in x's dtype: no cast pass
+            with _lib.on_device(dev):
+                _lib.check(lib.ms_conv3x3_bnbwd_nhwc_bf16(dy1.data_ptr(), wf1.data_ptr(), dx0.data_ptr(), B, H, W, C, C, ctypes.byref(r0), st),
+                           "ms_conv3x3_bnbwd_nhwc_bf16")
+                _lib.check(lib.ms_bn_bwd_apply_sums_nhwc(ctypes.byref(r0), dx0.data_ptr(), dxin.data_ptr(), int(dxin.dtype == torch.bfloat16),
+                                                         dgb[2].data_ptr(), dgb[3].data_ptr(), npix, C, st), "ms_bn_bwd_apply_sums_nhwc")
+        t0, t1, t2, t3, t4, t5 = ctx.dtypes
         zb = lambda b: arena.zeros_like(b) if b is not None else None           # d/d(conv bias) of BN(conv + bias) == 0
-        return (dx0, dw1, zb(ctx.b1), dgb1[0].to(t1), dgb1[1].to(t2), dw2, zb(ctx.b2), dgb2[0].to(t3), dgb2[1].to(t4), None, None)
+        return (dxin, dgb[2].to(t0), dgb[3].to(t1), dw1, zb(ctx.b1), dgb[0].to(t2), dgb[1].to(t3), dw2, zb(ctx.b2), dgb2[0].to(t4), dgb2[1].to(t5),
+                None, None, None)
 
 
-def _conv_bn_fold_ok(c1, bn1, c2, bn2, x):
+def _conv_bn_fold_ok(mods, x):
+    """The conv branch as `_ConvBnConvBn`: training-mode BatchNorms with affine + running statistics, bias-or-not 3x3 / stride 1 / padding 1
+    convolutions of equal width (a multiple of 16, <= 512), a channels_last-addressable CUDA input, bf16 autocast."""
+    bn0, c1, bn1, c2, bn2 = mods[0], mods[1], mods[2], mods[4], mods[5]
     def bn_ok(bn):
         return (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and type(bn) is torch.nn.BatchNorm2d
                 and bn.running_mean is not None and bn.weight.dtype == torch.float32)
     def conv_ok(c):
         return (type(c) is torch.nn.Conv2d and c.padding_mode == "zeros" and c.groups == 1 and c.weight.dtype == torch.float32
-                and _conv3x3_direct_ok(x, c.weight, c.stride, c.padding, c.dilation) and c.in_channels == c.out_channels == x.shape[1])
-    return (_BN_FOLD and _CONV_WGRAD and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] <= 512 and bn_ok(bn1) and bn_ok(bn2)
+                and tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1) and tuple(c.dilation) == (1, 1)
+                and c.in_channels == c.out_channels == x.shape[1])
+    C = x.shape[1] if x.dim() == 4 else 0
+    ps = _nhwc_pixel_stride(x) if x.dim() == 4 else None
+    return (_BN_FOLD and _CONV_WGRAD and _CONV_DIRECT and x.is_cuda and ps is not None and ps % 4 == 0 and x.data_ptr() % 16 == 0 and C % 16 == 0
+            and 16 <= C <= 512 and x.shape[2] * x.shape[3] >= _CONV_DIRECT_MIN_PIXELS and bn_ok(bn0) and bn_ok(bn1) and bn_ok(bn2)
             and conv_ok(c1) and conv_ok(c2) and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
@@ -570,14 +613,14 @@ def conv_branch(seq, x, premasked_out=False):
     if kinds != [nn.BatchNorm2d, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.ReLU]:
         y = seq(x.contiguous(memory_format=torch.channels_last))
         return (y, False) if premasked_out else y
-    x = batchnorm_relu(mods[0], x, False)
-    if _conv_bn_fold_ok(mods[1], mods[2], mods[4], mods[5], x):
+    if _conv_bn_fold_ok(mods, x):
         global FOLD_CALLS
         FOLD_CALLS += 1
         with torch.autocast(device_type="cuda", enabled=False):
-            x = _ConvBnConvBn.apply(x, mods[1].weight, mods[1].bias, mods[2].weight, mods[2].bias, mods[4].weight, mods[4].bias,
-                                    mods[5].weight, mods[5].bias, mods[2], mods[5])
+            x = _ConvBnConvBn.apply(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[2].weight, mods[2].bias,
+                                    mods[4].weight, mods[4].bias, mods[5].weight, mods[5].bias, mods[0], mods[2], mods[5])
     else:
+        x = batchnorm_relu(mods[0], x, False)
         x = _conv_then_bn(mods[1], mods[2], x)
         x = _conv_then_bn(mods[4], mods[5], x)
     y = conv1x1_relu(mods[7], x, premasked=premasked_out)

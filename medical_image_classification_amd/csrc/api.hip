@@ -42,6 +42,8 @@ void gemm_debug_tile(int bm, int bn);
 int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, hipStream_t s);
 int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
                              const MsBnFold *bn_out, hipStream_t s);
+int conv3x3_bnbwd_nhwc_dispatch(const void *dy, const void *w, void *dx, int batch, int H, int W, int Ci, int Co, const MsBnBwd *red, hipStream_t s);
+int bn_bwd_apply_sums_dispatch(const MsBnBwd *bn, const void *dy, void *dx, int dx_bf16, float *dgamma, float *dbeta, int64_t npix, int C, hipStream_t s);
 int bn_apply_sums_dispatch(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, hipStream_t s);
 int linear_bwd_ok(int N, int K);
 int linear_bwd_dispatch(const void *dy, int dy_f32, int64_t ld_dy, const void *x, int x_f32, int64_t ld_x, const void *w, int w_f32, void *dx,
@@ -147,6 +149,15 @@ int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H
 int ms_conv3x3_bn_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, const MsBnFold *bn_in, void *xhat,
                             const MsBnFold *bn_out, void *stream) {
     return ms::conv3x3_bn_nhwc_dispatch(x, w, y, batch, H, W, Ci, Co, bn_in, xhat, bn_out, (hipStream_t)stream);
+}
+
+int ms_conv3x3_bnbwd_nhwc_bf16(const void *dy, const void *w, void *dx, int batch, int H, int W, int Ci, int Co, const MsBnBwd *red, void *stream) {
+    return ms::conv3x3_bnbwd_nhwc_dispatch(dy, w, dx, batch, H, W, Ci, Co, red, (hipStream_t)stream);
+}
+
+int ms_bn_bwd_apply_sums_nhwc(const MsBnBwd *bn, const void *dy, void *dx, int dx_is_bf16, float *dgamma, float *dbeta, int64_t npix, int C,
+                              void *stream) {
+    return ms::bn_bwd_apply_sums_dispatch(bn, dy, dx, dx_is_bf16, dgamma, dbeta, npix, C, (hipStream_t)stream);
 }
 
 int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream) {

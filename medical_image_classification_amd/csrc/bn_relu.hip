@@ -253,6 +253,31 @@ bn_apply_sums_kernel(const unsigned short *__restrict__ x, const float *__restri
     }
 }
 
+// backward apply for a BatchNorm whose dgamma / dbeta arrive as replica rows a convolution's input-gradient epilogue accumulated
+// (MsBnBwd, conv3x3.hip BRED): totals from the rows in the prologue, then the same pass as bn_bwd_apply_kernel; dy is bf16
+template <typename T, typename TD>
+__global__ void __launch_bounds__(kBnThreads)
+bn_bwd_apply_sums_kernel(const T *__restrict__ x, int64_t xps, const unsigned short *__restrict__ dy, const float *__restrict__ gamma,
+                         const float *__restrict__ beta, const float *__restrict__ save_mean, const float *__restrict__ save_rstd, int relu,
+                         const float *__restrict__ sums, float *__restrict__ dgamma, float *__restrict__ dbeta, TD *__restrict__ dx,
+                         int64_t npix, int C, int ct, int rpi) {
+    const int t = threadIdx.x, c = blockIdx.y * ct + t % ct, r0 = t / ct;
+    if (c >= C) return;
+    float sb = 0.0f, sg = 0.0f;
+#pragma unroll 4
+    for (int r = 0; r < MS_BN_REPLICAS; ++r) { sb += sums[(r * 2) * C + c]; sg += sums[(r * 2 + 1) * C + c]; }
+    if (blockIdx.x == 0 && r0 == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+    const float inv_n = 1.0f / (float)npix;
+    const float mean = save_mean[c], rstd = save_rstd[c], g = gamma[c], b = beta[c];
+    const float k1 = sb * inv_n, k2 = sg * inv_n, gs = g * rstd;
+    for (int64_t p = (int64_t)blockIdx.x * rpi + r0; p < npix; p += (int64_t)gridDim.x * rpi) {
+        const float xh = (bn_ld(x + p * xps + c) - mean) * rstd;
+        float d = bn_ld(dy + p * C + c);
+        if (relu && fmaf(xh, g, b) <= 0.0f) d = 0.0f;
+        bn_st(dx + p * C + c, gs * (d - k1 - xh * k2));
+    }
+}
+
 static unsigned bn_blocks(int64_t npix, int rpi) {
     const int64_t need = (npix + (int64_t)rpi * 8 - 1) / ((int64_t)rpi * 8);         // >= 8 rows per thread
     return (unsigned)(need < 1 ? 1 : (need > kBnMaxBlocks ? kBnMaxBlocks : need));
@@ -279,6 +304,25 @@ int bn_fwd_dispatch(const void *x, int x_bf16, int64_t xps, const float *shift, 
     if (x_bf16 && y_bf16) MS_BN_APPLY(bf, bf); else if (x_bf16) MS_BN_APPLY(bf, float);
     else if (y_bf16) MS_BN_APPLY(float, bf); else MS_BN_APPLY(float, float);
 #undef MS_BN_APPLY
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int bn_bwd_apply_sums_dispatch(const MsBnBwd *bn, const void *dy, void *dx, int dx_bf16, float *dgamma, float *dbeta, int64_t npix, int C,
+                               hipStream_t s) {
+    if (!bn || !bn->x_pre || !bn->gamma || !bn->beta || !bn->save_mean || !bn->save_rstd || !bn->sums || !dy || !dx || !dgamma || !dbeta)
+        return MS_ERR_NULL;
+    if (npix <= 0 || C <= 0) return npix == 0 && C > 0 ? MS_OK : MS_ERR_SHAPE;
+    if (bn->x_pre_pixel_stride < C) return MS_ERR_STRIDE;
+    const BnGeom g = bn_geom(C);
+    const unsigned nblk = bn_blocks(npix, g.rows_per_iter);
+    const dim3 grid(nblk, (unsigned)g.ncb), block(kBnThreads);
+    using bf = unsigned short;
+#define MS_BN_BAS(TI, TD)                                                                                                              \
+    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<TI, TD>), grid, block, 0, s, (const TI *)bn->x_pre, bn->x_pre_pixel_stride, (const bf *)dy, bn->gamma, \
+                       bn->beta, bn->save_mean, bn->save_rstd, bn->relu, bn->sums, dgamma, dbeta, (TD *)dx, npix, C, g.ct, g.rows_per_iter)
+    if (bn->x_pre_is_f32) { if (dx_bf16) { MS_BN_BAS(float, bf); } else { MS_BN_BAS(float, float); } }
+    else { if (dx_bf16) { MS_BN_BAS(bf, bf); } else { MS_BN_BAS(bf, float); } }
+#undef MS_BN_BAS
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 

@@ -46,6 +46,16 @@ struct BnFoldDev {
     float *save_mean, *save_rstd;
     float momentum, eps, inv_n, unbias;          // inv_n = 1 / pixels, unbias = n / (n - 1)
 };
+// BRED (the input-gradient launch, dx = conv3x3(dy, w')): the BatchNorm BEHIND this convolution's input (the one whose output the forward
+//   convolved) needs sum dy' and sum dy' * xhat over all pixels, dy' = dx * [its ReLU passed]: the epilogue has dx in registers, loads the
+//   pre-normalisation activation of the same pixels, and accumulates both sums into replica rows -- the bn_bwd_reduce pass (a read of x
+//   and of dx) and its finalize launch disappear; ms_bn_bwd_apply_sums_nhwc reads the rows.
+struct BnBwdDev {
+    const void *xpre; int xpre_f32; int64_t xps;
+    const float *gamma, *beta, *mean, *rstd;
+    int relu;
+    float *sums;                                 // [kBnRep][2][C]: sum dy' (dbeta), sum dy' * xhat (dgamma)
+};
 __device__ __forceinline__ float bf_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 __device__ __forceinline__ unsigned bf_pack(float a, float b) {
@@ -70,12 +80,12 @@ template <int CTRL> __device__ __forceinline__ float row_ror_add(float x) {
 // first version ran `load -> LDS store` loops with run-time trip counts: ten dependent global-load round trips per slice, which
 // -- not the MFMAs, not LDS -- were the kernel's time.)  Slices of 32 channels use v_mfma_f32_16x16x32_bf16 (one ds_read_b128 per
 // fragment), a 16-channel tail slice the K = 16 form.
-template <int NB, bool BNIN = false, bool STATS = false>
+template <int NB, bool BNIN = false, bool STATS = false, bool BRED = false>
 // (NB = 4, MedMamba-B's 64-channel blocks: 60 KB of LDS and 3 x 16 accumulator registers more -- two workgroups per CU is what fits)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB >= 4 ? 2 : MS_CONV_WAVES, NB >= 4 ? 2 : MS_CONV_WAVES)))
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
                     int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img, BnFoldDev bin, unsigned short *__restrict__ xhat,
-                    BnFoldDev bout) {
+                    BnFoldDev bout, BnBwdDev bred) {
     __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kXP];
     __shared__ __attribute__((aligned(16))) unsigned short sW[9 * NB * 16 * kWP];
     __shared__ __attribute__((aligned(16))) float sScale[BNIN ? kBnMaxC : 4], sShift[BNIN ? kBnMaxC : 4];
@@ -264,28 +274,66 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             }
         }
     }
-    if constexpr (STATS) {
-        // per output channel: sum (y - p), sum (y - p)^2 over the tile's in-image pixels, y as stored (bf16-rounded)
-        float s1[NB][4], s2[NB][4], pv[NB][4];
+    if constexpr (STATS || BRED) {
+        float s1[NB][4], s2[NB][4];
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = co0 + n * 16 + fq * 4 + r;
-                pv[n][r] = c < Co ? bout.running_mean[c] - (bout.shift ? bout.shift[c] : 0.f) : 0.f;
-                s1[n][r] = 0.f; s2[n][r] = 0.f;
-            }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const bool valid = h0 + wv * 2 + m < H && w0 + fr < W;
+            for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
+        if constexpr (STATS) {
+            // per output channel: sum (y - p), sum (y - p)^2 over the tile's in-image pixels, y as stored (bf16-rounded)
+            float pv[NB][4];
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float yv = (float)(__bf16)acc[m][n][r];
-                    const float d = valid ? yv - pv[n][r] : 0.f;
-                    s1[n][r] += d; s2[n][r] = fmaf(d, d, s2[n][r]);
+                    const int c = co0 + n * 16 + fq * 4 + r;
+                    pv[n][r] = c < Co ? bout.running_mean[c] - (bout.shift ? bout.shift[c] : 0.f) : 0.f;
                 }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bool valid = h0 + wv * 2 + m < H && w0 + fr < W;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float yv = (float)(__bf16)acc[m][n][r];
+                        const float d = valid ? yv - pv[n][r] : 0.f;
+                        s1[n][r] += d; s2[n][r] = fmaf(d, d, s2[n][r]);
+                    }
+            }
+        } else {
+            // per channel: s1 = sum dy', s2 = sum dy' * xhat with dy' = dx (as stored) * [relu passed], xhat from the pre-normalisation tensor
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int c = co0 + n * 16 + fq * 4;
+                if (c >= Co) continue;
+                const float4 mu = *reinterpret_cast<const float4 *>(bred.mean + c), rs = *reinterpret_cast<const float4 *>(bred.rstd + c);
+                const float4 ga = *reinterpret_cast<const float4 *>(bred.gamma + c), be = *reinterpret_cast<const float4 *>(bred.beta + c);
+                const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int hh = h0 + wv * 2 + m, ww = w0 + fr;
+                    if (hh >= H || ww >= W) continue;
+                    const int64_t pix = ((int64_t)img * H + hh) * W + ww;
+                    float xv[4];
+                    if (bred.xpre_f32) {
+                        const float4 t = *reinterpret_cast<const float4 *>(static_cast<const float *>(bred.xpre) + pix * bred.xps + c);
+                        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                    } else {
+                        const uint2 t = *reinterpret_cast<const uint2 *>(static_cast<const unsigned short *>(bred.xpre) + pix * bred.xps + c);
+                        xv[0] = bf_lo(t.x); xv[1] = bf_hi(t.x); xv[2] = bf_lo(t.y); xv[3] = bf_hi(t.y);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (xv[r] - muv[r]) * rsv[r];
+                        float d = (float)(__bf16)acc[m][n][r];
+                        if (bred.relu && fmaf(xh, gav[r], bev[r]) <= 0.f) d = 0.f;
+                        s1[n][r] += d; s2[n][r] = fmaf(d, xh, s2[n][r]);
+                    }
+                }
+            }
         }
         // sum over the 16 pixel lanes of a row (lane bits 0-3): four row rotations, every lane ends with the row's total
 #pragma unroll
@@ -312,8 +360,8 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             if (co0 + c < Co) {
                 const float v = (red[(0 * 2 + st) * (NB * 16) + c] + red[(1 * 2 + st) * (NB * 16) + c]) +
                                 (red[(2 * 2 + st) * (NB * 16) + c] + red[(3 * 2 + st) * (NB * 16) + c]);
-                atomicAdd(bout.sums + ((blockIdx.x % kBnRep) * 2 + st) * Co + co0 + c, v);
-                if (blockIdx.x == 0 && st == 0)                 // the pivot these sums are taken around, for the consumer
+                atomicAdd((STATS ? bout.sums : bred.sums) + ((blockIdx.x % kBnRep) * 2 + st) * Co + co0 + c, v);
+                if (STATS && blockIdx.x == 0 && st == 0)        // the pivot these sums are taken around, for the consumer
                     bout.sums[kBnRep * 2 * Co + co0 + c] = bout.running_mean[co0 + c] - (bout.shift ? bout.shift[co0 + c] : 0.f);
             }
         }
@@ -332,8 +380,31 @@ int conv3x3_nhwc_dispatch(const void *x, const void *w, void *y, int batch, int 
     const dim3 grid((unsigned)(batch * tiles_per_img), (unsigned)((Co + cb - 1) / cb));
     using bf = unsigned short;
     const BnFoldDev none = {};
-    if (cb == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<4>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none);
-    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<3>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none);
+    const BnBwdDev nob = {};
+    if (cb == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<4>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none, nob);
+    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<3>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none, nob);
+    return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+// dx = conv3x3(dy, w') (the input gradient) with the reduce pass of the BatchNorm behind the convolution's input in its epilogue
+int conv3x3_bnbwd_nhwc_dispatch(const void *dy, const void *w, void *dx, int batch, int H, int W, int Ci, int Co, const MsBnBwd *red, hipStream_t s) {
+    if (!dy || !w || !dx || !red || !red->x_pre || !red->gamma || !red->beta || !red->save_mean || !red->save_rstd || !red->sums) return MS_ERR_NULL;
+    if (batch < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0) return MS_ERR_SHAPE;
+    if (red->x_pre_pixel_stride < Co || red->x_pre_pixel_stride % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(red->x_pre) & (red->x_pre_is_f32 ? 15 : 7)) != 0)
+        return MS_ERR_STRIDE;
+    if (batch == 0) return MS_OK;
+    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH;
+    const int tiles_per_img = tiles_w * tiles_h;
+    const int cb = (Co % 64 == 0 && Co % 48 != 0) ? 64 : 48;
+    const dim3 grid((unsigned)(batch * tiles_per_img), (unsigned)((Co + cb - 1) / cb));
+    using bf = unsigned short;
+    const BnFoldDev none = {};
+    BnBwdDev d = {};
+    d.xpre = red->x_pre; d.xpre_f32 = red->x_pre_is_f32; d.xps = red->x_pre_pixel_stride; d.gamma = red->gamma; d.beta = red->beta;
+    d.mean = red->save_mean; d.rstd = red->save_rstd; d.relu = red->relu; d.sums = red->sums;
+    if (cb == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<4, false, false, true>), grid, dim3(256), 0, s, (const bf *)dy, (const bf *)w, (bf *)dx, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none, d);
+    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<3, false, false, true>), grid, dim3(256), 0, s, (const bf *)dy, (const bf *)w, (bf *)dx, H, W, Ci, Co, tiles_w, tiles_per_img, none, (bf *)nullptr, none, d);
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
 }
 
@@ -366,8 +437,9 @@ int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, i
     using bf = unsigned short;
     const int64_t npix = (int64_t)batch * H * W;
     const BnFoldDev di = bn_fold_dev(bn_in, npix), dz = bn_fold_dev(bn_out, npix);
+    const BnBwdDev nob = {};
 #define MS_CONV_BN(NBv, I, O) hipLaunchKernelGGL((conv3x3_nhwc_kernel<NBv, I, O>), grid, dim3(256), 0, s, (const bf *)x, (const bf *)w, (bf *)y, H, W, Ci, Co, \
-        tiles_w, tiles_per_img, di, (bf *)xhat, dz)
+        tiles_w, tiles_per_img, di, (bf *)xhat, dz, nob)
     if (cb == 64) { if (bn_in && bn_out) MS_CONV_BN(4, true, true); else if (bn_in) MS_CONV_BN(4, true, false); else MS_CONV_BN(4, false, true); }
     else          { if (bn_in && bn_out) MS_CONV_BN(3, true, true); else if (bn_in) MS_CONV_BN(3, true, false); else MS_CONV_BN(3, false, true); }
 #undef MS_CONV_BN
