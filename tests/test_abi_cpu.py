@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_layout_matches_c(tmp_path):
     """sizeof/offsetof of the ctypes mirrors == what a C compiler sees in medscan.h."""
-    from medical_image_classification_amd._lib import (ADAM_CHUNK, ADAM_MAX_TENSORS, BN_REPLICAS, MsAdamDesc, MsBnFold, MsCastDesc, MsScanBwdParams,
+    from medical_image_classification_amd._lib import (ADAM_CHUNK, ADAM_MAX_TENSORS, BN_REPLICAS, MsAdamDesc, MsBnBwd, MsBnFold, MsCastDesc, MsScanBwdParams,
                                                        MsScanParams)
     src = tmp_path / "lay.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "medscan.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
@@ -42,7 +42,8 @@ def test_struct_layout_matches_c(tmp_path):
                    'printf("%zu %zu %zu\\n",offsetof(MsScanParams,dt_w),offsetof(MsScanParams,dt_rank),offsetof(MsScanBwdParams,ddt_w));'
                    'printf("%zu %zu %zu\\n",sizeof(MsCastDesc),offsetof(MsCastDesc,n),offsetof(MsCastDesc,taps));'
                    'printf("%zu %zu %d %d\\n",sizeof(MsAdamDesc),offsetof(MsAdamDesc,n),MS_ADAM_CHUNK,MS_ADAM_MAX_TENSORS);'
-                   'printf("%zu %zu %zu %d %d\\n",sizeof(MsBnFold),offsetof(MsBnFold,save_mean),offsetof(MsBnFold,eps),MS_BN_REPLICAS,MS_BN_FOLD_FLOATS(48));return 0;}\n')
+                   'printf("%zu %zu %zu %d %d\\n",sizeof(MsBnFold),offsetof(MsBnFold,save_mean),offsetof(MsBnFold,eps),MS_BN_REPLICAS,MS_BN_FOLD_FLOATS(48));'
+                   'printf("%zu %zu %zu %zu\\n",sizeof(MsBnBwd),offsetof(MsBnBwd,x_pre_pixel_stride),offsetof(MsBnBwd,relu),offsetof(MsBnBwd,sums));return 0;}\n')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
@@ -51,7 +52,8 @@ def test_struct_layout_matches_c(tmp_path):
             MsScanParams.dt_w.offset, MsScanParams.dt_rank.offset, MsScanBwdParams.ddt_w.offset,
             ctypes.sizeof(MsCastDesc), MsCastDesc.n.offset, MsCastDesc.taps.offset,
             ctypes.sizeof(MsAdamDesc), MsAdamDesc.n.offset, ADAM_CHUNK, ADAM_MAX_TENSORS,
-            ctypes.sizeof(MsBnFold), MsBnFold.save_mean.offset, MsBnFold.eps.offset, BN_REPLICAS, (2 * BN_REPLICAS + 1) * 48]
+            ctypes.sizeof(MsBnFold), MsBnFold.save_mean.offset, MsBnFold.eps.offset, BN_REPLICAS, (2 * BN_REPLICAS + 1) * 48,
+            ctypes.sizeof(MsBnBwd), MsBnBwd.x_pre_pixel_stride.offset, MsBnBwd.relu.offset, MsBnBwd.sums.offset]
     assert got == want
 
 

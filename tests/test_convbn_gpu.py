@@ -1,5 +1,5 @@
-"""The conv branch's inner BatchNorms folded into the 3x3 convolutions (csrc/conv3x3.hip `BNIN` / `STATS`, ms_bn_apply_sums_nhwc; host:
-block_ops._ConvBnConvBn) against (a) the unfused kernel sequence of the same package (statistics / finalize / apply launches), which the
+"""The conv branch's BatchNorms folded into the 3x3 convolutions (csrc/conv3x3.hip `BNIN` / `STATS` forward, `BRED` backward,
+ms_bn_apply_sums_nhwc / ms_bn_bwd_apply_sums_nhwc; host: block_ops._ConvBnConvBn) against (a) the unfused kernel sequence of the same package (statistics / finalize / apply launches), which the
 existing tests hold to float64 torch, and (b) float64 torch directly for the statistics the epilogue accumulates.
 Reference: MedMamba.py:517-527 (`conv33conv33conv11`), applied at :533-535.
 
