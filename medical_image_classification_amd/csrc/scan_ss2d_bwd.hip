@@ -261,8 +261,8 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         const float *sBl = sB + sg * 2, *sCl = sC + sg * 2;          // this lane's state pair inside a position row
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
-            if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
-            if (FULL || kb * 4 < len) {
+            if constexpr (FULL && MS_BWD_FULLPATH == 1) __builtin_amdgcn_sched_barrier(0);
+            if ((FULL && MS_BWD_FULLPATH == 1) || kb * 4 < len) {       // FULLPATH 2: the batch guards stay (same scheduling regions as the generic path)
 #pragma unroll
                 for (int l = kb * 4; l < kb * 4 + 4; ++l) {
                     if ((l & 3) == 0) ckp[l >> 2] = hp;
@@ -315,8 +315,8 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
 #pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
-            if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
-            if (FULL || lb < len) {
+            if constexpr (FULL && MS_BWD_FULLPATH == 1) __builtin_amdgcn_sched_barrier(0);
+            if ((FULL && MS_BWD_FULLPATH == 1) || lb < len) {
                 v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4], aj[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
