@@ -496,6 +496,11 @@ typedef struct MsBnBwd {
 int ms_conv3x3_bnbwd_nhwc_bf16(const void *dy, const void *w, void *dx, int batch, int H, int W, int Ci, int Co, const MsBnBwd *red, void *stream);
 int ms_bn_bwd_apply_sums_nhwc(const MsBnBwd *bn, const void *dy, void *dx, int dx_is_bf16, float *dgamma, float *dbeta, int64_t npix, int C,
                               void *stream);
+/* The same reduce on the epilogue of C = A B^T... in the input-gradient form of ms_gemm_bf16 (A (M, K) fp32 / bf16, B (K, N) in memory, C (M, N)
+ * stored as fp32 (c_mode 0) or bf16 (1)): the 1x1 convolution behind the last BatchNorm of the conv branch (MedMamba.py:524-525).
+ * bn->x_pre: bf16, (M, N) rows; N % 4 == 0. */
+int ms_gemm_bf16_bnbwd(const void *A, int a_is_f32, int64_t lda, const void *B, int b_is_f32, int64_t ldb, void *C, int c_mode, int64_t ldc, int M,
+                       int N, int K, const MsBnBwd *bn, void *stream);
 /* The consumer for a BatchNorm that is not followed by a 3x3 convolution: y = [relu](bn(x)) from the producer's sums, one pass over
  * x (npix, C) bf16 -> y (npix, C) bf16; also writes save_mean / save_rstd and updates the running statistics. */
 int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream);

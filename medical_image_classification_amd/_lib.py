@@ -78,7 +78,7 @@ EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks",
            "ms_dwconv3x3_silu_nhwc_bwd", "ms_dwconv3x3_silu_nhwc_bwd_scratch_floats", "ms_ln_gate_fwd", "ms_ln_gate_fwd_keep", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd", "ms_layernorm_taps_fwd", "ms_layernorm_taps_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_fwd_act", "ms_dtproj_bwd", "ms_dtproj_bwd_scratch_floats", "ms_bn_relu_nhwc_fwd",
            "ms_bn_relu_nhwc_bwd", "ms_bn_scratch_floats", "ms_ssd_chunk_carry", "ms_ssd_chunk_fwd", "ms_ssd_chunk_fwd_off", "ms_ssd_chunk_bwd_off", "ms_ssd_chunk_bwd", "ms_rms_gate_fwd", "ms_rms_gate_bwd", "ms_gemm_bf16", "ms_gemm_f32", "ms_gemm_bf16_bias_act", "ms_gemm_bf16_wgrad_bias",
-           "ms_cast_bf16_multi", "ms_patchify4_bf16", "ms_adam_multi", "ms_block_tail_bwd_relu", "ms_block_head_bwd", "ms_debug_gemm_tile", "ms_conv3x3_nhwc_bf16", "ms_conv3x3_wgrad", "ms_conv3x3_wgrad_scratch_floats", "ms_conv3x3_bn_nhwc_bf16", "ms_bn_apply_sums_nhwc", "ms_conv3x3_bnbwd_nhwc_bf16", "ms_bn_bwd_apply_sums_nhwc", "ms_linear_bwd_ok", "ms_linear_bwd_bf16", "ms_spin", "ms_abi_version", "ms_status_string")
+           "ms_cast_bf16_multi", "ms_patchify4_bf16", "ms_adam_multi", "ms_block_tail_bwd_relu", "ms_block_head_bwd", "ms_debug_gemm_tile", "ms_conv3x3_nhwc_bf16", "ms_conv3x3_wgrad", "ms_conv3x3_wgrad_scratch_floats", "ms_conv3x3_bn_nhwc_bf16", "ms_bn_apply_sums_nhwc", "ms_conv3x3_bnbwd_nhwc_bf16", "ms_bn_bwd_apply_sums_nhwc", "ms_gemm_bf16_bnbwd", "ms_linear_bwd_ok", "ms_linear_bwd_bf16", "ms_spin", "ms_abi_version", "ms_status_string")
 ABI_VERSION = 9
 
 _lib = None
@@ -166,6 +166,7 @@ def lib():
     h.ms_bn_apply_sums_nhwc.argtypes = [c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_vp]
     h.ms_conv3x3_bnbwd_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
     h.ms_bn_bwd_apply_sums_nhwc.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_vp]
+    h.ms_gemm_bf16_bnbwd.argtypes = [c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp]
     h.ms_linear_bwd_ok.argtypes = [c_int, c_int]
     h.ms_linear_bwd_bf16.argtypes = [c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_int, c_int, c_vp]
     h.ms_spin.argtypes = [ctypes.c_longlong, c_vp]

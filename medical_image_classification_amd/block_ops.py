@@ -490,18 +490,22 @@ def _bn_bwd_desc(xpre, ps, gamma, beta, save, relu, sums):
 
 
 class _ConvBnConvBn(torch.autograd.Function):
-    """x2 = relu(bn2(conv2(relu(bn1(conv1(bn0(x))))))) for training-mode BatchNorms on a channels_last activation
-    (`conv33conv33conv11[0:7]`, MedMamba.py:517-524).  Forward: bn0 as statistics / finalize / apply (its input comes from outside), then
-    THREE launches for the rest -- conv1 accumulates the statistics of its output in its epilogue; conv2 normalises + rectifies conv1's
-    output while it stages its input tiles (writing the normalised activation `x1` as a side output for the backward) and accumulates
-    the statistics of ITS output; one apply pass produces x2 (was 2 convolutions + 2 x (statistics, finalize, apply)).
-    Backward: the reduce passes of bn1 and bn0 ride in the epilogues of the input-gradient launches of conv2 and conv1 (`BRED`), their apply
-    passes read the replica rows; bn2 (whose incoming gradient is the 1x1 convolution's) keeps its three launches.
-    The conv biases never touch the activations (a constant in front of a mean subtraction): they enter the running means only and get
-    exact zero gradients."""
+    """The whole conv branch `relu(conv1x1(relu(bn2(conv2(relu(bn1(conv1(bn0(x)))))))))` of SS_Conv_SSM (`conv33conv33conv11`,
+    MedMamba.py:517-527) for training-mode BatchNorms on a channels_last activation, as ONE autograd node.
+    Forward: bn0 as statistics / finalize / apply (its input comes from outside); conv1 accumulates the statistics of its output in its
+    epilogue; conv2 normalises + rectifies conv1's output while it stages its input tiles (writing the normalised activation `x1` as a
+    side output for the backward) and accumulates the statistics of ITS output; one apply pass produces x2; the 1x1 convolution + bias +
+    ReLU is ms_gemm_bf16_bias_act.  (Was 2 convolutions + 3 x (statistics, finalize, apply) + the GEMM.)
+    Backward: the reduce pass of every BatchNorm rides in the epilogue of the launch that produces its incoming gradient -- bn2's in the
+    1x1 convolution's input-gradient GEMM (ms_gemm_bf16_bnbwd), bn1's and bn0's in the input-gradient launches of conv2 and conv1
+    (`BRED`); their apply passes read the replica rows and write dgamma / dbeta.
+    The 3x3 convolutions' biases never touch the activations (a constant in front of a mean subtraction): they enter the running means
+    only and get exact zero gradients."""
 
     @staticmethod
-    def forward(ctx, x, g0, be0, w1, b1, g1, be1, w2, b2, g2, be2, bn0, bn1, bn2):
+    def forward(ctx, x, g0, be0, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, bn0, bn1, bn2, premasked):
+        # w3 / b3: the 1x1 convolution + ReLU that ends the branch (MedMamba.py:525-526) on ms_gemm_bf16_bias_act; in the backward its input
+        # gradient launch carries bn2's reduce (ms_gemm_bf16_bnbwd).  premasked: the incoming gradient is already masked by that ReLU.
         B, C, H, W = x.shape
         npix = B * H * W
         lib = _lib.lib()
@@ -529,33 +533,56 @@ class _ConvBnConvBn(torch.autograd.Function):
             _lib.check(lib.ms_conv3x3_bn_nhwc_bf16(y1.data_ptr(), wb2.data_ptr(), y2.data_ptr(), B, H, W, C, C, ctypes.byref(d1), x1.data_ptr(),
                                                    ctypes.byref(d2), st), "ms_conv3x3_bn_nhwc_bf16")
             _lib.check(lib.ms_bn_apply_sums_nhwc(y2.data_ptr(), ctypes.byref(d2), 1, x2.data_ptr(), npix, C, st), "ms_bn_apply_sums_nhwc")
-        ctx.save_for_backward(x, x0, y1, x1, y2, g0f, be0f, g1f, be1f, g2f, be2f, save)
-        ctx.w1, ctx.w2, ctx.b1, ctx.b2, ctx.ps = w1, w2, b1, b2, ps
+        from .gemm_ops import gemm
+        Co = w3.shape[0]
+        w3m = w3.detach().view(Co, C)
+        out = gemm(x2.permute(0, 2, 3, 1).reshape(npix, C), w3m, out_dtype=torch.bfloat16, bias=b3.detach() if b3 is not None else None, relu=True)
+        ctx.save_for_backward(x, x0, y1, x1, y2, x2, out, g0f, be0f, g1f, be1f, g2f, be2f, save)
+        ctx.w1, ctx.w2, ctx.w3, ctx.b1, ctx.b2, ctx.b3, ctx.ps, ctx.premasked = w1, w2, w3m, b1, b2, b3, ps, premasked
         ctx.dtypes = (g0.dtype, be0.dtype, g1.dtype, be1.dtype, g2.dtype, be2.dtype)
-        return x2
+        return out.view(B, H, W, Co).permute(0, 3, 1, 2)                # NCHW-shaped, channels_last memory
 
     @staticmethod
-    def backward(ctx, dx2):
-        x, x0, y1, x1, y2, g0f, be0f, g1f, be1f, g2f, be2f, save = ctx.saved_tensors
+    def backward(ctx, dy):
+        from .gemm_ops import weight_grad, wgrad_bias_ok
+        x, x0, y1, x1, y2, x2, out, g0f, be0f, g1f, be1f, g2f, be2f, save = ctx.saved_tensors
         B, C, H, W = x.shape
         npix = B * H * W
         dev = x.device
         shadow.invalidate(dev)
         lib = _lib.lib()
-        if dx2.dtype not in (torch.float32, torch.bfloat16):
-            dx2 = dx2.float()
-        dx2 = dx2.contiguous(memory_format=torch.channels_last)
         new = lambda dt=torch.bfloat16: torch.empty((B, C, H, W), device=dev, dtype=dt, memory_format=torch.channels_last)
-        st = _stream(dx2)
-        # bn2: its incoming gradient comes from the 1x1 convolution -- the three-launch backward
-        dy2, dgb2 = new(), torch.empty((2, C), device=dev, dtype=torch.float32)
+        st = _stream(dy)
+        # the 1x1 convolution + ReLU: dz = dy * [out > 0] (or dy itself when the consumer has applied the mask), dW3 = dz^T x2 with the
+        # column sums of dz (the bias gradient) on the same launch, dx2 = dz W3 with bn2's reduce in its epilogue
+        w3m = ctx.w3
+        Co = w3m.shape[0]
+        dz = dy.permute(0, 2, 3, 1).reshape(npix, Co)
+        if not ctx.premasked:
+            dz = torch.ops.aten.threshold_backward(dz.contiguous(), out, 0)
+        if dz.dtype not in (torch.bfloat16, torch.float32) or not dz.is_contiguous():
+            dz = dz.contiguous().float()
+        x2m = x2.permute(0, 2, 3, 1).reshape(npix, C)
+        want_db = ctx.b3 is not None and ctx.needs_input_grad[12]
+        dw3 = db3 = None
+        if ctx.needs_input_grad[11]:
+            if want_db and wgrad_bias_ok(dz, x2m):
+                db3 = arena.zeros((Co,), dev)
+                dw3 = weight_grad(dz, x2m, dbias=db3)
+            else:
+                dw3 = weight_grad(dz, x2m)
+        if want_db and db3 is None:
+            db3 = dz.sum(dim=0, dtype=torch.float32)
+        bsums = arena.zeros((3, 2 * _lib.BN_REPLICAS * C), dev)
+        dgb = torch.empty((6, C), device=dev, dtype=torch.float32)
+        r2 = _bn_bwd_desc(y2, C, g2f, be2f, save[4:6], True, bsums[2])
+        dx2, dy2 = new(), new()
         with _lib.on_device(dev):
-            _lib.check(lib.ms_bn_relu_nhwc_bwd(y2.data_ptr(), 1, C, dx2.data_ptr(), int(dx2.dtype == torch.bfloat16), g2f.data_ptr(), be2f.data_ptr(),
-                                               save[4].data_ptr(), save[5].data_ptr(), 1, dy2.data_ptr(), 1, dgb2[0].data_ptr(), dgb2[1].data_ptr(),
-                                               _bn_scratch(dev, C).data_ptr(), npix, C, st), "ms_bn_relu_nhwc_bwd")
+            _lib.check(lib.ms_gemm_bf16_bnbwd(dz.data_ptr(), int(dz.dtype == torch.float32), dz.stride(0), w3m.data_ptr(), int(w3m.dtype == torch.float32),
+                                              w3m.stride(0), dx2.data_ptr(), 1, C, npix, C, Co, ctypes.byref(r2), st), "ms_gemm_bf16_bnbwd")
+            _lib.check(lib.ms_bn_bwd_apply_sums_nhwc(ctypes.byref(r2), dx2.data_ptr(), dy2.data_ptr(), 1, dgb[4].data_ptr(), dgb[5].data_ptr(), npix, C,
+                                                     st), "ms_bn_bwd_apply_sums_nhwc")
         dw2 = _conv3x3_wgrad(x1, dy2, ctx.w2.shape) if ctx.needs_input_grad[7] else None
-        bsums = arena.zeros((2, 2 * _lib.BN_REPLICAS * C), dev)
-        dgb = torch.empty((4, C), device=dev, dtype=torch.float32)
         # conv2's input gradient with bn1's reduce in its epilogue, then bn1's apply from the rows
         r1 = _bn_bwd_desc(y1, C, g1f, be1f, save[2:4], True, bsums[0])
         dx1, dy1 = new(), new()
@@ -579,14 +606,14 @@ class _ConvBnConvBn(torch.autograd.Function):
                                                          dgb[2].data_ptr(), dgb[3].data_ptr(), npix, C, st), "ms_bn_bwd_apply_sums_nhwc")
         t0, t1, t2, t3, t4, t5 = ctx.dtypes
         zb = lambda b: arena.zeros_like(b) if b is not None else None           # d/d(conv bias) of BN(conv + bias) == 0
-        return (dxin, dgb[2].to(t0), dgb[3].to(t1), dw1, zb(ctx.b1), dgb[0].to(t2), dgb[1].to(t3), dw2, zb(ctx.b2), dgb2[0].to(t4), dgb2[1].to(t5),
-                None, None, None)
+        return (dxin, dgb[2].to(t0), dgb[3].to(t1), dw1, zb(ctx.b1), dgb[0].to(t2), dgb[1].to(t3), dw2, zb(ctx.b2), dgb[4].to(t4), dgb[5].to(t5),
+                dw3.view(Co, C, 1, 1) if dw3 is not None else None, db3, None, None, None, None)
 
 
 def _conv_bn_fold_ok(mods, x):
     """The conv branch as `_ConvBnConvBn`: training-mode BatchNorms with affine + running statistics, bias-or-not 3x3 / stride 1 / padding 1
     convolutions of equal width (a multiple of 16, <= 512), a channels_last-addressable CUDA input, bf16 autocast."""
-    bn0, c1, bn1, c2, bn2 = mods[0], mods[1], mods[2], mods[4], mods[5]
+    bn0, c1, bn1, c2, bn2, c3 = mods[0], mods[1], mods[2], mods[4], mods[5], mods[7]
     def bn_ok(bn):
         return (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and type(bn) is torch.nn.BatchNorm2d
                 and bn.running_mean is not None and bn.weight.dtype == torch.float32)
@@ -598,7 +625,9 @@ def _conv_bn_fold_ok(mods, x):
     ps = _nhwc_pixel_stride(x) if x.dim() == 4 else None
     return (_BN_FOLD and _CONV_WGRAD and _CONV_DIRECT and x.is_cuda and ps is not None and ps % 4 == 0 and x.data_ptr() % 16 == 0 and C % 16 == 0
             and 16 <= C <= 512 and x.shape[2] * x.shape[3] >= _CONV_DIRECT_MIN_PIXELS and bn_ok(bn0) and bn_ok(bn1) and bn_ok(bn2)
-            and conv_ok(c1) and conv_ok(c2) and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+            and conv_ok(c1) and conv_ok(c2) and type(c3) is torch.nn.Conv2d and c3.kernel_size == (1, 1) and c3.stride == (1, 1)
+            and c3.padding == (0, 0) and c3.groups == 1 and c3.in_channels == C and c3.out_channels % 8 == 0 and c3.weight.dtype == torch.float32
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
 def conv_branch(seq, x, premasked_out=False):
@@ -617,8 +646,10 @@ def conv_branch(seq, x, premasked_out=False):
         global FOLD_CALLS
         FOLD_CALLS += 1
         with torch.autocast(device_type="cuda", enabled=False):
-            x = _ConvBnConvBn.apply(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[2].weight, mods[2].bias,
-                                    mods[4].weight, mods[4].bias, mods[5].weight, mods[5].bias, mods[0], mods[2], mods[5])
+            y = _ConvBnConvBn.apply(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[2].weight, mods[2].bias,
+                                    mods[4].weight, mods[4].bias, mods[5].weight, mods[5].bias, mods[7].weight, mods[7].bias,
+                                    mods[0], mods[2], mods[5], bool(premasked_out))
+        return (y, True) if premasked_out else y
     else:
         x = batchnorm_relu(mods[0], x, False)
         x = _conv_then_bn(mods[1], mods[2], x)

@@ -45,6 +45,8 @@ int conv3x3_bn_nhwc_dispatch(const void *x, const void *w, void *y, int batch, i
 int conv3x3_bnbwd_nhwc_dispatch(const void *dy, const void *w, void *dx, int batch, int H, int W, int Ci, int Co, const MsBnBwd *red, hipStream_t s);
 int bn_bwd_apply_sums_dispatch(const MsBnBwd *bn, const void *dy, void *dx, int dx_bf16, float *dgamma, float *dbeta, int64_t npix, int C, hipStream_t s);
 int bn_apply_sums_dispatch(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, hipStream_t s);
+int gemm_bf16_bnbwd_dispatch(const void *A, int a_f32, int64_t lda, const void *B, int b_f32, int64_t ldb, void *C, int c_mode, int64_t ldc, int M,
+                             int N, int K, const MsBnBwd *bn, hipStream_t stream);
 int linear_bwd_ok(int N, int K);
 int linear_bwd_dispatch(const void *dy, int dy_f32, int64_t ld_dy, const void *x, int x_f32, int64_t ld_x, const void *w, int w_f32, void *dx,
                         int dx_bf16, int64_t ld_dx, float *dW, int M, int N, int K, hipStream_t s);
@@ -162,6 +164,11 @@ int ms_bn_bwd_apply_sums_nhwc(const MsBnBwd *bn, const void *dy, void *dx, int d
 
 int ms_bn_apply_sums_nhwc(const void *x, const MsBnFold *bn, int relu, void *y, int64_t npix, int C, void *stream) {
     return ms::bn_apply_sums_dispatch(x, bn, relu, y, npix, C, (hipStream_t)stream);
+}
+
+int ms_gemm_bf16_bnbwd(const void *A, int a_is_f32, int64_t lda, const void *B, int b_is_f32, int64_t ldb, void *C, int c_mode, int64_t ldc, int M,
+                       int N, int K, const MsBnBwd *bn, void *stream) {
+    return ms::gemm_bf16_bnbwd_dispatch(A, a_is_f32, lda, B, b_is_f32, ldb, C, c_mode, ldc, M, N, K, bn, (hipStream_t)stream);
 }
 
 int ms_linear_bwd_ok(int N, int K) { return ms::linear_bwd_ok(N, K); }

@@ -78,13 +78,27 @@ struct TileStage {
     }
 };
 
+// The reduce pass of a BatchNorm's backward riding on the store modes' epilogue (ms_gemm_bf16_bnbwd: dx = dz W of the conv branch's 1x1
+// convolution, MedMamba.py:525, whose result is the gradient w.r.t. the output of the BatchNorm + ReLU in front of it): per output
+// column (= channel) sum dy' and sum dy' * xhat over the rows (= pixels), dy' = C[m][n] as stored * [relu passed], xhat from the
+// pre-normalisation activation xpre[m][n] (bf16) -- into MS_BN_REPLICAS replica rows, as conv3x3.hip's BRED epilogue does.
+struct GemmRed {
+    const unsigned short *xpre; int64_t xps;
+    const float *gamma, *beta, *mean, *rstd;
+    int relu;
+    float *sums;                                   // nullptr: no reduction
+};
+template <int CTRL> __device__ __forceinline__ float gemm_row_ror_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, x), CTRL, 0xF, 0xF, true));
+}
+
 // CMODE: 0 = fp32 store, 1 = bf16 store, 2 = fp32 atomic add (split-K partial), 3 = fp32 atomic add into C^T
 // BM x BN outputs per workgroup; the 4 waves split the ROWS (MT = BM / 64 tiles of 16 rows each), every wave spans all BN
 // columns (TNT = BN / 16 tiles): an activation row block is read once for up to 192 output columns.
-template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR, int CMODE>
+template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR, int CMODE, bool RED = false>
 __global__ void __launch_bounds__(256)
 gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int k_per_split,
-                 const float *__restrict__ bias, int relu) {
+                 const float *__restrict__ bias, int relu, GemmRed red) {
     constexpr int TNT = BN / 16, MT = BM / 64;
     __shared__ __attribute__((aligned(16))) unsigned short sA[TileStage<BM, AF32, ATR>::kLds];
     __shared__ __attribute__((aligned(16))) unsigned short sB[TileStage<BN, BF32, BTR>::kLds];
@@ -191,6 +205,62 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
         }
         return;
     }
+    if constexpr (RED) {        // its own instantiations: as a run-time branch the accumulators below cost EVERY input-gradient launch
+        {                       // registers (x_proj's dx at stage 0: 65 -> 88 us)
+            float s1[TNT][4], s2[TNT][4];
+#pragma unroll
+            for (int a = 0; a < TNT; ++a) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
+                const int n = n0 + a * 16 + fq * 4;                 // N % 4 == 0 (host): a lane's 4 columns are in or out together
+                if (n >= N) continue;
+                const float4 mu = *reinterpret_cast<const float4 *>(red.mean + n), rs = *reinterpret_cast<const float4 *>(red.rstd + n);
+                const float4 ga = *reinterpret_cast<const float4 *>(red.gamma + n), be = *reinterpret_cast<const float4 *>(red.beta + n);
+                const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    const int m = m0 + w * (16 * MT) + b * 16 + fr;
+                    if (m >= M) continue;
+                    const uint2 t = *reinterpret_cast<const uint2 *>(red.xpre + (int64_t)m * red.xps + n);
+                    const float xv[4] = {__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xFFFF0000u),
+                                         __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xFFFF0000u)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (xv[r] - muv[r]) * rsv[r];
+                        float d = CMODE == 1 ? (float)(__bf16)acc[a][b][r] : acc[a][b][r];
+                        if (red.relu && fmaf(xh, gav[r], bev[r]) <= 0.f) d = 0.f;
+                        s1[a][r] += d; s2[a][r] = fmaf(d, xh, s2[a][r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TNT; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                       // sum over the 16 row lanes (lane bits 0-3)
+                    s1[a][r] = gemm_row_ror_add<0x121>(gemm_row_ror_add<0x122>(gemm_row_ror_add<0x124>(gemm_row_ror_add<0x128>(s1[a][r]))));
+                    s2[a][r] = gemm_row_ror_add<0x121>(gemm_row_ror_add<0x122>(gemm_row_ror_add<0x124>(gemm_row_ror_add<0x128>(s2[a][r]))));
+                }
+            __syncthreads();                                        // every wave has read its last fragments: sA is free
+            float *sr = reinterpret_cast<float *>(sA);              // [wave][2][BN]
+            if (fr == 0) {
+#pragma unroll
+                for (int a = 0; a < TNT; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sr[(w * 2 + 0) * BN + a * 16 + fq * 4 + r] = s1[a][r];
+                        sr[(w * 2 + 1) * BN + a * 16 + fq * 4 + r] = s2[a][r];
+                    }
+            }
+            __syncthreads();
+            for (int e = tid; e < 2 * BN; e += 256) {
+                const int st = e / BN, c = e - st * BN;
+                if (n0 + c < N)
+                    atomicAdd(red.sums + ((blockIdx.x % MS_BN_REPLICAS) * 2 + st) * N + n0 + c,
+                              (sr[(0 * 2 + st) * BN + c] + sr[(1 * 2 + st) * BN + c]) + (sr[(2 * 2 + st) * BN + c] + sr[(3 * 2 + st) * BN + c]));
+            }
+        }
+    }
     // D[i][j]: i = n within the tile (row 4*fq + r of the accumulator), j = m within the tile (column fr)
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
@@ -244,16 +314,22 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
 
 template <int BM, int BN, bool AF32, bool BF32, bool ATR, bool BTR>
 static void launch_c(int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B, void *C, int M, int N, int K, int64_t lda,
-                     int64_t ldb, int64_t ldc, int kps, const float *bias, int relu) {
+                     int64_t ldb, int64_t ldc, int kps, const float *bias, int relu, GemmRed red) {
     // the accumulating modes exist for the weight gradient (both operands transposed) only
     if constexpr (!(ATR && BTR)) { if (c_mode >= 2) return; }
+    if (red.sums != nullptr) {              // BatchNorm backward reduce in the epilogue: input-gradient form, 64-column tiles, bf16 store
+        if constexpr (!ATR && BTR && BN == 64)
+            if (c_mode == 1)
+                hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red);
+        return;
+    }
     switch (c_mode) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 0>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); break;
+        case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 0>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red); break;
         default:
             if constexpr (ATR && BTR) {
-                if (c_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);
-                else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);
+                if (c_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red);
+                else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AF32, BF32, ATR, BTR, 3>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red);
             }
             break;
     }
@@ -261,9 +337,9 @@ static void launch_c(int c_mode, dim3 grid, hipStream_t s, const void *A, const 
 
 template <int BM, int BN>
 static void launch_layout(bool af32, bool bf32, bool atr, bool btr, int c_mode, dim3 grid, hipStream_t s, const void *A, const void *B,
-                          void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int kps, const float *bias, int relu) {
+                          void *C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int kps, const float *bias, int relu, GemmRed red) {
 #define MS_GEMM_CASE(AF, BF, AT, BT) \
-    if (af32 == AF && bf32 == BF && atr == AT && btr == BT) { launch_c<BM, BN, AF, BF, AT, BT>(c_mode, grid, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu); return; }
+    if (af32 == AF && bf32 == BF && atr == AT && btr == BT) { launch_c<BM, BN, AF, BF, AT, BT>(c_mode, grid, s, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red); return; }
     // the combinations the projections use (activations bf16 or fp32, weights fp32)
     MS_GEMM_CASE(false, false, false, false)  // y = x(bf16) W(bf16 copy)^T
     MS_GEMM_CASE(true, false, false, false)
@@ -288,8 +364,8 @@ static bool combo_built(bool af32, bool bf32, bool atr, bool btr, int c_mode) {
 static int g_force_bm = 0, g_force_bn = 0;   // experiments (ms_debug_gemm_tile): 0 = the heuristic below
 void gemm_debug_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
-int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
-                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream) {
+static int gemm_impl(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
+                     int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, GemmRed red, hipStream_t stream) {
     if (!A || !B || !C) return MS_ERR_NULL;
     // the epilogue belongs to the store modes; in c_mode 2 `bias` is the row-sum OUTPUT of the weight-gradient form (see the kernel)
     if ((relu && c_mode >= 2) || (bias && c_mode == 3) || (bias && c_mode == 2 && !(a_trans && b_trans))) return MS_ERR_SHAPE;
@@ -314,17 +390,36 @@ int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const
         const int per = (N + passes - 1) / passes;
         bn = per <= 64 ? 64 : per <= 128 ? 128 : 192;
     }
-    if (g_force_bn) bn = g_force_bn;
+    if (red.sums != nullptr) bn = 64;           // the reduce epilogue is built for 64-column tiles
+    else if (g_force_bn) bn = g_force_bn;
     const int ny = (N + bn - 1) / bn;
     // row block 64 instead of 128 when 128-row blocks would not give every CU four workgroups
     const bool small = (int64_t)((M + 127) / 128) * ny * nz < 1024;
     const int bm = g_force_bm ? g_force_bm : (small ? 64 : 128);
     const dim3 grid((M + bm - 1) / bm, ny, nz);
 #define MS_GEMM_TILE(BM_, BN_) \
-    if (bm == BM_ && bn == BN_) launch_layout<BM_, BN_>(a_f32, b_f32, a_trans, b_trans, c_mode, grid, stream, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu);
+    if (bm == BM_ && bn == BN_) launch_layout<BM_, BN_>(a_f32, b_f32, a_trans, b_trans, c_mode, grid, stream, A, B, C, M, N, K, lda, ldb, ldc, kps, bias, relu, red);
     MS_GEMM_TILE(128, 64) MS_GEMM_TILE(128, 128) MS_GEMM_TILE(128, 192) MS_GEMM_TILE(64, 64) MS_GEMM_TILE(64, 128) MS_GEMM_TILE(64, 192)
 #undef MS_GEMM_TILE
     return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+}
+
+int gemm_bf16_dispatch(const void *A, int a_f32, int a_trans, int64_t lda, const void *B, int b_f32, int b_trans, int64_t ldb, void *C,
+                       int c_mode, int64_t ldc, int M, int N, int K, int k_splits, const float *bias, int relu, hipStream_t stream) {
+    return gemm_impl(A, a_f32, a_trans, lda, B, b_f32, b_trans, ldb, C, c_mode, ldc, M, N, K, k_splits, bias, relu, GemmRed{}, stream);
+}
+
+// C = A B (b_trans form: B is (K, N) in memory), stored as fp32 / bf16, with the BatchNorm backward reduce of the result in the epilogue
+int gemm_bf16_bnbwd_dispatch(const void *A, int a_f32, int64_t lda, const void *B, int b_f32, int64_t ldb, void *C, int c_mode, int64_t ldc, int M,
+                             int N, int K, const MsBnBwd *bn, hipStream_t stream) {
+    if (!bn || !bn->x_pre || !bn->gamma || !bn->beta || !bn->save_mean || !bn->save_rstd || !bn->sums) return MS_ERR_NULL;
+    if (c_mode < 0 || c_mode > 1) return MS_ERR_SHAPE;
+    if (bn->x_pre_is_f32 || N % 4 != 0 || c_mode != 1) return MS_ERR_UNSUPPORTED;
+    if (bn->x_pre_pixel_stride < N || bn->x_pre_pixel_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(bn->x_pre) & 7) != 0) return MS_ERR_STRIDE;
+    GemmRed red;
+    red.xpre = static_cast<const unsigned short *>(bn->x_pre); red.xps = bn->x_pre_pixel_stride; red.gamma = bn->gamma; red.beta = bn->beta;
+    red.mean = bn->save_mean; red.rstd = bn->save_rstd; red.relu = bn->relu; red.sums = bn->sums;
+    return gemm_impl(A, a_f32, 0, lda, B, b_f32, 1, ldb, C, c_mode, ldc, M, N, K, 1, nullptr, 0, red, stream);
 }
 
 }  // namespace ms
