@@ -471,6 +471,36 @@ def test_vfefm_fusion_step_at_224():
     assert not torch.equal(before, net.final_conv.weight.detach())
 
 
+def test_vfefm_fusion_step_at_224_batch_32():
+    """BASELINE.json configs[4] as it is benchmarked: 32 pairs of 3 x 224 x 224, the model CrossMamba/train.py:80-91 builds, two
+    bf16-autocast fusion steps (the second one runs with refreshed bf16 weight copies and a re-used arena): finite loss terms that move,
+    a finite gradient on every used parameter, peak device memory below 100 GiB (the chunk states of the stage-0 SSD scans are
+    recomputed in the backward above MEDSCAN_SSD_KEEP_STATE_GB)."""
+    from medical_image_classification_amd.train_fusion import build_fusion_model, fusion_step, synthetic_pair
+    from medical_image_classification_amd.fusion_loss import FusionLoss
+    from medical_image_classification_amd.train import make_adam
+    import gc
+    torch.manual_seed(0)
+    gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()                                  # whatever earlier tests of this process still hold
+    net = build_fusion_model().to(dev()).train()
+    opt = make_adam(net.parameters(), lr=2e-4)
+    crit = FusionLoss().to(dev())
+    vis, ir = synthetic_pair(32, 224, dev())
+    t1 = fusion_step(net, opt, crit, vis, ir, torch.bfloat16)
+    t2 = fusion_step(net, opt, crit, vis, ir, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).item() for t in t1 + t2)
+    assert float(t2[0]) != float(t1[0])                                   # the weights moved between the two steps
+    used = 0
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all().item(), n
+            used += 1
+    assert used > 1000
+    assert torch.cuda.max_memory_allocated() - base < 100 * 2 ** 30, (torch.cuda.max_memory_allocated() - base) / 2 ** 30
+
+
 @pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 4, 16), (1, 9, 5, 32, 2, 16), (2, 28, 28, 96, 3, 32)])
 def test_ssd_backward_all_slices_in_one_launch(cfg, monkeypatch):
     """ms_selective_scan_bwd with MS_SCAN_BC_MAP(4) (csrc/scan_bwd_ssd.hip: the four direction slices of the state axis in one
