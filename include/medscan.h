@@ -129,7 +129,11 @@ typedef struct MsScanParams {
     float *out;
     float *x;
     const float *dt_x, *dt_w;               /* MS_SCAN_DT_FUSED operands (else ignored) */
-    int32_t dt_rank, reserved0;
+    int32_t dt_rank;
+    int32_t segments;                       /* >= 2 (forward, SS2D fast path, inference): scan the sequence in that many segments in
+                                             * parallel -- B * 4 * D / 8 waves do not fill the chip at small batch.  `x` is then a WORKSPACE of
+                                             * ms_scan_seg_floats(batch, dim, segments) floats instead of the saved states (two passes over
+                                             * the recurrence + a carry over the segments; same result up to rounding).  0 / 1: off. */
 } MsScanParams;
 
 /*
@@ -157,6 +161,8 @@ int ms_selective_scan_fwd(const MsScanParams *p, void *stream);
 int ms_selective_scan_bwd(const MsScanBwdParams *p, void *stream);
 /* number of saved states per row for a sequence length (host-side sizing of `x`) */
 int ms_scan_n_chunks(int seqlen);
+/* floats of the workspace `x` of a segmented forward (MsScanParams.segments >= 2; dstate 16) */
+int64_t ms_scan_seg_floats(int batch, int dim, int segments);
 
 /*
  * 4-direction cross-scan and cross-merge (MedMamba.py:393-395 and :420-424,476), fp32, contiguous.

@@ -29,7 +29,7 @@ class MsScanParams(ctypes.Structure):
             "B_batch_stride", "B_group_stride", "B_dstate_stride", "B_l_stride",
             "C_batch_stride", "C_group_stride", "C_dstate_stride", "C_l_stride")]
         + [(n, c_vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "out", "x", "dt_x", "dt_w")]
-        + [(n, c_i32) for n in ("dt_rank", "reserved0")]
+        + [(n, c_i32) for n in ("dt_rank", "segments")]
     )
 
 
@@ -73,7 +73,7 @@ BN_REPLICAS = 16
 ADAM_CHUNK, ADAM_MAX_TENSORS = 4096, 448
 CAST_CHUNK, CAST_TILE_O, CAST_TILE_I, CAST_TILE_MAX_TAPS = 2048, 64, 16, 9
 
-EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_cross_scan",
+EXPORTS = ("ms_selective_scan_fwd", "ms_selective_scan_bwd", "ms_scan_n_chunks", "ms_scan_seg_floats", "ms_cross_scan",
            "ms_cross_merge", "ms_cross_scan_nhwc", "ms_cross_merge_nhwc", "ms_dwconv3x3_silu_fwd", "ms_dwconv3x3_silu_bwd", "ms_dwconv3x3_silu_nhwc_fwd",
            "ms_dwconv3x3_silu_nhwc_bwd", "ms_dwconv3x3_silu_nhwc_bwd_scratch_floats", "ms_ln_gate_fwd", "ms_ln_gate_fwd_keep", "ms_ln_gate_bwd", "ms_layernorm_fwd", "ms_layernorm_bwd", "ms_layernorm_taps_fwd", "ms_layernorm_taps_bwd",
            "ms_block_tail_fwd", "ms_block_tail_bwd", "ms_dtproj_fwd", "ms_dtproj_fwd_act", "ms_dtproj_bwd", "ms_dtproj_bwd_scratch_floats", "ms_bn_relu_nhwc_fwd",
@@ -167,6 +167,7 @@ def lib():
     h.ms_conv3x3_bnbwd_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
     h.ms_bn_bwd_apply_sums_nhwc.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_vp]
     h.ms_gemm_bf16_bnbwd.argtypes = [c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp]
+    h.ms_scan_seg_floats.argtypes = [c_int, c_int, c_int]
     h.ms_linear_bwd_ok.argtypes = [c_int, c_int]
     h.ms_linear_bwd_bf16.argtypes = [c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_int, c_int, c_vp]
     h.ms_spin.argtypes = [ctypes.c_longlong, c_vp]
@@ -176,6 +177,7 @@ def lib():
         getattr(h, name).restype = ctypes.c_int
     h.ms_dwconv3x3_silu_nhwc_bwd_scratch_floats.restype = c_i64
     h.ms_dtproj_bwd_scratch_floats.restype = c_i64
+    h.ms_scan_seg_floats.restype = c_i64
     h.ms_conv3x3_wgrad_scratch_floats.restype = c_i64
     if h.ms_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{_SO}: ABI version {h.ms_abi_version()} != {ABI_VERSION} (stale build?)")

@@ -220,6 +220,9 @@ int ms_selective_scan_bwd(const MsScanBwdParams *p, void *stream) {
 }
 
 int ms_scan_n_chunks(int seqlen) { return seqlen <= 0 ? 0 : (seqlen + MS_SCAN_CHUNK - 1) / MS_SCAN_CHUNK; }
+int64_t ms_scan_seg_floats(int batch, int dim, int segments) {
+    return (batch <= 0 || dim <= 0 || segments < 2) ? 0 : 2ll * batch * segments * 16 * dim;      // two planes of [batch][segment][16 states][dim]
+}
 
 int ms_cross_scan(const float *x, float *xs, int batch, int dim, int H, int W, void *stream) {
     return ms::cross_scan_dispatch(x, xs, batch, dim, H, W, (hipStream_t)stream);

@@ -322,6 +322,7 @@ int scan_fwd_dispatch(const MsScanParams &p, hipStream_t stream) {
     if (p.batch == 0 || p.seqlen == 0) return MS_OK;
     const int n_chunks = (p.seqlen + kCL - 1) / kCL;
     if (ss2d_fast_ok(p)) return ss2d_fwd_launch(p, n_chunks, stream);
+    if (p.segments >= 2) return MS_ERR_UNSUPPORTED;                         // segments (p.x = workspace): the SS2D fast path only
     if (p.delta_softplus & MS_SCAN_DT_FUSED) return MS_ERR_UNSUPPORTED;     // the fused projection exists on the fast path only
     if (use_cw8(p, false)) {
         switch (pick_npl(p.dstate, 8)) {

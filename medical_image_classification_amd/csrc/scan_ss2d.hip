@@ -63,9 +63,17 @@ __device__ __forceinline__ void wg_to_work(int bid, int npairs, int ncg, int &pa
 // forward:  replaces selective_scan_fwd_kernel (selective_scan_fwd_kernel.cuh:67-303) + the eager ops of
 // MedMamba.py:393-395 (cross-scan), :400 (dt_proj, when DTF), :420-424 (inverse permutations of the cross-merge)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CW, bool DTF>
+// SEG (inference at small batch: B * 4 * D / CW waves do not fill the chip, and each walks all L positions one after the other): the
+// sequence is cut into `segments` runs of `cps` chunks, blockIdx.y = the segment.
+//   SEG 1: scan the segment from the ZERO state with no output; at its end store the state h_end and the product of its decays P per
+//          (channel, state) into the workspace p.x: plane 0 [batch][segment][state][dim] = h_end, plane 1 = P.
+//   (ss2d_seg_carry_kernel: plane 0 [s] <- the state ENTERING segment s: H = P[s-1] H + h_end[s-1], sequential over the few segments)
+//   SEG 2: the plain forward over the segment, started from plane 0 [s].
+// Twice the recurrence work, `segments` times the parallelism; the recurrence is linear in the state, so the result is the
+// unsegmented one up to rounding (h entering a segment is formed as P * H + h_end instead of position by position).
+template <int CW, bool DTF, int SEG = 0>
 __global__ void __launch_bounds__(64 * (32 / CW))
-ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
+ss2d_fwd_kernel(const MsScanParams p, const int n_chunks, const int cps = 0, const int segments = 1) {
     constexpr int SG = 64 / CW, NPL = kN / SG, NP2 = NPL / 2, NW = 32 / CW, NT = 64 * NW;
     using V = VecIO<CW>;
     constexpr int QPP = V::QPP, PPI = V::PPI, NEV = V::NEV;
@@ -99,14 +107,20 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
     const bool active = c < nvalid, quad_ok = my4 < nvalid;
     const int dsafe = min(d0 + (active ? c : 0), p.dim - 1);    // channel whose parameters this lane reads
 
-    v2f A2[NP2], h[NP2];
+    const int seg = SEG ? (int)blockIdx.y : 0;
+    const int ch_begin = SEG ? seg * cps : 0, ch_end = SEG ? min(n_chunks, ch_begin + cps) : n_chunks;
+    if (SEG && ch_begin >= ch_end) return;                        // (uniform over the workgroup: before any barrier)
+    float *seg_h = SEG ? p.x + (((int64_t)b * segments + seg) * kN) * p.dim : nullptr;            // plane 0 row block of this (batch, segment)
+    float *seg_p = SEG ? seg_h + (int64_t)p.batch * segments * kN * p.dim : nullptr;               // plane 1
+    v2f A2[NP2], h[NP2], Pd[SEG == 1 ? NP2 : 1];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int n = sg * NPL + i;
         float av = active ? p.A[dsafe * p.A_d_stride + n * p.A_dstate_stride] : 0.0f;
         if ((p.delta_softplus & MS_SCAN_A_IS_LOG) && active) av = -__expf(av);
         A2[i / 2][i % 2] = av * kLog2e;
-        h[i / 2][i % 2] = 0.0f;
+        h[i / 2][i % 2] = (SEG == 2 && active) ? seg_h[(int64_t)n * p.dim + dsafe] : 0.0f;
+        if constexpr (SEG == 1) Pd[i / 2][i % 2] = 1.0f;
     }
     // MS_SCAN_DELTA_ACTIVATED: delta already holds softplus(raw + bias) (ms_dtproj_fwd_act); wave-uniform
     const bool pre = !DTF && (p.delta_softplus & MS_SCAN_DELTA_ACTIVATED) != 0;
@@ -176,9 +190,9 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
             }
         }
     };
-    fetch(0);
+    fetch(ch_begin);
 
-    for (int ch = 0; ch < n_chunks; ++ch) {
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int l0 = ch * kCL, len = min(kCL, L - l0);
         __syncthreads();                        // everyone is done with the previous chunk's shared tiles
 #pragma unroll
@@ -231,7 +245,7 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
             st4(dst + 4, make_float4(dl[2], dl[2] * us[2], dl[3], dl[3] * us[3]));
         }
         wave_sync();
-        if (ch + 1 < n_chunks) fetch(ch + 1);  // lands while this chunk is computed
+        if (ch + 1 < ch_end) fetch(ch + 1);    // lands while this chunk is computed
 
 #ifndef MS_FWD_UNROLL
 #define MS_FWD_UNROLL 8
@@ -254,10 +268,12 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
                     const v2f Bv = *reinterpret_cast<const v2f *>(bp + 2 * q), Cv = *reinterpret_cast<const v2f *>(cp + 2 * q);
                     const v2f a = exp2_pk(splat(dd.x) * A2[q]);
                     h[q] = pk_fma(a, h[q], splat(dd.y) * Bv);
-                    y2 = q == 0 ? Cv * h[q] : pk_fma(Cv, h[q], y2);
+                    if constexpr (SEG == 1) Pd[q] = Pd[q] * a;
+                    else y2 = q == 0 ? Cv * h[q] : pk_fma(Cv, h[q], y2);
                 }
                 y[j] = y2.x + y2.y;
             }
+            if constexpr (SEG == 1) continue;                       // no output in the first pass
             const float yt = sum_groups_scatter4<CW>(y, lane);
             // 8-channel waves: both lanes of the last butterfly pair (lane bit 3) hold the total and store it to the same word -- no
             // predicate, and the last DPP add folds into one v_add_f32_dpp (behind `if (owner)` it was a v_mov_b32_dpp + v_add inside
@@ -266,13 +282,13 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
         }
         };
         if (len == kCL) sweep(std::false_type()); else sweep(std::true_type());
-        if (p.x != nullptr && active) {
+        if (SEG == 0 && p.x != nullptr && active) {
 #pragma unroll
             for (int i = 0; i < NPL; ++i)
                 p.x[(((int64_t)b * n_chunks + ch) * kN + sg * NPL + i) * p.dim + dsafe] = h[i / 2][i % 2];
         }
         wave_sync();
-        {
+        if constexpr (SEG != 1) {
             const int *tab = spos[ch & 1];
 #pragma unroll
             for (int k = 0; k < NEV; ++k) {
@@ -289,12 +305,36 @@ ss2d_fwd_kernel(const MsScanParams p, const int n_chunks) {
         }
         wave_sync();
     }
+    if constexpr (SEG == 1) {
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                seg_h[(int64_t)(sg * NPL + i) * p.dim + dsafe] = h[i / 2][i % 2];
+                seg_p[(int64_t)(sg * NPL + i) * p.dim + dsafe] = Pd[i / 2][i % 2];
+            }
+        }
+    }
 #ifdef MS_CLOCK
     if (lane == 0) {
         atomicAdd(&ms_clock_acc[0], __builtin_amdgcn_s_memtime() - ck0);
         atomicAdd(&ms_clock_acc[1], __builtin_amdgcn_s_memrealtime() - rk0);
     }
 #endif
+}
+
+// plane 0 [b][s][n][d] = h_end of segment s (from zero state), plane 1 = product of its decays  ->  plane 0 [s] = state entering s
+__global__ void __launch_bounds__(256)
+ss2d_seg_carry_kernel(float *__restrict__ ws, int batch, int segments, int64_t row /* kN * dim */) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)batch * row) return;
+    const int64_t b = e / row, r = e - b * row;
+    float *h = ws + (b * segments) * row + r, *pd = h + (int64_t)batch * segments * row;
+    float H = 0.0f;
+    for (int s2 = 0; s2 < segments; ++s2) {
+        const float he = h[(int64_t)s2 * row], pv = pd[(int64_t)s2 * row];
+        h[(int64_t)s2 * row] = H;
+        H = fmaf(pv, H, he);
+    }
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -329,6 +369,21 @@ int ss2d_fwd_launch(const MsScanParams &p, int n_chunks, hipStream_t stream) {
     // 8-channel waves (8 state groups, 2 states per lane) when 16-channel waves would leave the chip under-filled
     static const int cw_env = [] { const char *e = getenv("MEDSCAN_FWD_CW"); return e ? atoi(e) : 0; }();      // experiments: force 8 / 16
     const bool cw8 = cw_env ? cw_env == 8 : (int64_t)p.batch * p.n_groups * ncg * 2 < 4096;      // measured (MedMamba-T bs 64): stage 1 (3072 16-channel waves) 177 vs 190 us with 8-channel waves; stage 2 (6144) equal
+    // MS_SCAN_SEGMENTS (p.segments >= 2, p.x = workspace of ms_scan_seg_floats(..) floats, no saved states): the sequence in segments
+    // (inference at small batch); 8-channel waves
+    const int segs = p.segments >= 2 ? (p.segments < n_chunks ? p.segments : n_chunks) : 1;
+    if (segs >= 2) {
+        if (!p.x || (p.delta_softplus & (MS_SCAN_ACCUMULATE | MS_SCAN_DELTA_OUT))) return MS_ERR_UNSUPPORTED;
+        const int cps = (n_chunks + segs - 1) / segs;
+        const dim3 g2(grid.x, (unsigned)segs);
+        if (dtf) hipLaunchKernelGGL((ss2d_fwd_kernel<8, true, 1>), g2, dim3(256), 0, stream, p, n_chunks, cps, segs);
+        else     hipLaunchKernelGGL((ss2d_fwd_kernel<8, false, 1>), g2, dim3(256), 0, stream, p, n_chunks, cps, segs);
+        const int64_t row = (int64_t)kN * p.dim;
+        hipLaunchKernelGGL(ss2d_seg_carry_kernel, dim3((unsigned)((p.batch * row + 255) / 256)), dim3(256), 0, stream, p.x, p.batch, segs, row);
+        if (dtf) hipLaunchKernelGGL((ss2d_fwd_kernel<8, true, 2>), g2, dim3(256), 0, stream, p, n_chunks, cps, segs);
+        else     hipLaunchKernelGGL((ss2d_fwd_kernel<8, false, 2>), g2, dim3(256), 0, stream, p, n_chunks, cps, segs);
+        return hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_LAUNCH;
+    }
     if (cw8) {
         if (dtf) hipLaunchKernelGGL((ss2d_fwd_kernel<8, true>), grid, dim3(256), 0, stream, p, n_chunks);
         else     hipLaunchKernelGGL((ss2d_fwd_kernel<8, false>), grid, dim3(256), 0, stream, p, n_chunks);

@@ -75,6 +75,17 @@ def dwconv3x3_silu_nhwc(x, weight, bias):
     return _DWConvSiLUNHWC.apply(x, weight, bias)
 
 
+_SEG_TARGET_WAVES = int(os.environ.get("MEDSCAN_SCAN_SEG_WAVES", "2048"))      # 0: never segment
+
+
+def _scan_segments(waves, n_chunks):
+    """Segments of the sequence for an inference forward scan: enough to put ~_SEG_TARGET_WAVES waves on the chip, at least 4 chunks
+    (128 positions) per segment; 1 = unsegmented."""
+    if _SEG_TARGET_WAVES <= 0 or waves >= _SEG_TARGET_WAVES // 2 or n_chunks < 8:
+        return 1
+    return max(1, min(n_chunks // 4, -(-_SEG_TARGET_WAVES // waves)))
+
+
 def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R, a_is_log=False):
     B, L, D = xc.shape[0], H * W, xc.shape[-1]
     C = R + 2 * N
@@ -90,7 +101,7 @@ def _ss2d_params(P, xc, proj, delta, A, Ds, dt_bias, out, x_state, H, W, N, R, a
     P.B, P.C = proj.data_ptr() + 4 * R, proj.data_ptr() + 4 * (R + N)
     P.D, P.delta_bias = Ds.data_ptr(), dt_bias.data_ptr()
     P.out = out.data_ptr() if out is not None else None
-    P.x = x_state.data_ptr()
+    P.x = x_state.data_ptr() if x_state is not None else None
 
 
 # dt_rank up to which ms_dtproj_* are used (above it: batched GEMMs).  R <= 4: the register-tiled kernels (stage 0 of MedMamba-T,
@@ -394,6 +405,13 @@ class _SS2DInner(torch.autograd.Function):
             if fuse_dt:
                 P.delta_softplus |= 128             # MS_SCAN_DT_FUSED
                 P.dt_x, P.dt_w, P.dt_rank, P.x = proj.data_ptr(), wdt.data_ptr(), R, None
+            if not need_bwd:
+                # inference at small batch: B * 4 * D / 8 waves walk all L positions one after the other and do not fill the chip (batch 1 at
+                # stage 0 of MedMamba-T: 48 waves for 1 024 SIMDs) -- scan the sequence in segments (MsScanParams.segments, csrc/scan_ss2d.hip)
+                segs = _scan_segments(B * 4 * ((D + 7) // 8), lib.ms_scan_n_chunks(L))
+                if segs >= 2 and N == 16 and D % 4 == 0:
+                    seg_ws = torch.empty(lib.ms_scan_seg_floats(B, 4 * D, segs), device=dev, dtype=torch.float32)
+                    P.x, P.segments = seg_ws.data_ptr(), segs
             if fuse_dt_train:
                 P.delta_softplus |= 128 | 1024      # MS_SCAN_DT_FUSED | MS_SCAN_DELTA_OUT
                 P.dt_x, P.dt_w, P.dt_rank = proj.data_ptr(), wdt.data_ptr(), R
@@ -666,7 +684,7 @@ def _ssd_params(P, xc, delta, A_col, D_full, bias_full, y4, x_state, B, L, H, W,
     P.D = D_full.data_ptr() if D_full is not None else None
     P.delta_bias = bias_full.data_ptr()
     P.out = y4.data_ptr() if y4 is not None else None
-    P.x = x_state.data_ptr()
+    P.x = x_state.data_ptr() if x_state is not None else None
 
 
 def ssd_scan_merge_pixel(xc, As, Dsv, dt_bias, d_ssm, d_state, nheads, headdim, d_has_hdim):

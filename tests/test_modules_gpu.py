@@ -871,3 +871,86 @@ def test_batchnorm_statistics_with_a_large_mean():
     assert float((bn.running_var.double() - ref.running_var).abs().max()) <= 2e-4 * float(ref.running_var.abs().max())
     assert float((bn.running_mean.double() - ref.running_mean).abs().max()) <= 1e-6 * float(ref.running_mean.abs().max())
     assert float((xd.grad.double() - xr.grad).abs().max()) <= 2e-3 * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,D,Hh,R,segs,fused", [(1, 96, 56, 3, 13, False), (2, 48, 28, 3, 4, False), (1, 192, 28, 6, 24, True), (1, 96, 19, 3, 3, True),
+                                                  (3, 40, 23, 3, 100, False)])
+def test_segmented_forward_scan_matches_unsegmented(B, D, Hh, R, segs, fused):
+    """MsScanParams.segments (csrc/scan_ss2d.hip SEG 1 / carry / SEG 2: the sequence scanned in parallel segments for inference at small
+    batch) == the unsegmented forward of the same operands, SS2D addressing, all four directions, with and without the Delta projection
+    inside the kernel, ragged lengths (L = 361, 529: partial last chunk) and more segments than chunks (clamped).  The recurrence is
+    linear in the state, so only the rounding differs (the state entering a segment is P * H + h_end): 2e-5 of max|y|."""
+    import ctypes
+    from medical_image_classification_amd import _lib
+    from medical_image_classification_amd._lib import MsScanParams
+    from medical_image_classification_amd.ss2d_fused import _ss2d_params
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    L, N, C = Hh * Hh, 16, R + 32
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + D + Hh)
+    A = torch.log(torch.arange(1, N + 1, device=dev, dtype=torch.float32)).repeat(4 * D, 1).contiguous() + 0.1 * torch.randn(4 * D, N, device=dev, generator=g)
+    Dp = torch.randn(4 * D, device=dev, generator=g)
+    bias = torch.rand(4 * D, device=dev, generator=g) - 4.0
+    xc = torch.randn(B, Hh, Hh, D, device=dev, generator=g)
+    proj = torch.randn(B, L, 4, C, device=dev, generator=g)
+    wdt = torch.randn(4, D, R, device=dev, generator=g) * 0.3
+    delta = torch.einsum("blkr,kdr->kbld", proj[..., :R], wdt).contiguous()
+    outs = []
+    for s_ in (0, segs):
+        y4 = torch.zeros(4, B, L, D, device=dev)
+        P = MsScanParams()
+        _ss2d_params(P, xc, proj, None if fused else delta, A, Dp, bias, y4, None, Hh, Hh, N, R, a_is_log=True)
+        if fused:
+            P.delta_softplus |= 128
+            P.dt_x, P.dt_w, P.dt_rank = proj.data_ptr(), wdt.data_ptr(), R
+        ws = None
+        if s_:
+            ws = torch.empty(lib.ms_scan_seg_floats(B, 4 * D, s_), device=dev)
+            P.x, P.segments = ws.data_ptr(), s_
+        _lib.check(lib.ms_selective_scan_fwd(ctypes.byref(P), _lib.current_stream_ptr(dev)), "scan")
+        torch.cuda.synchronize()
+        outs.append(y4)
+    ref, got = outs
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), float((got - ref).abs().max() / ref.abs().max())
+
+
+def test_eval_forward_at_batch_1_takes_the_segmented_scan_and_matches_training_mode_output():
+    """SS2D in eval() / no_grad() at batch 1 (48 scan waves at stage 0 of MedMamba-T): ss2d_inner picks the segmented scan
+    (`_scan_segments`); its output == the output of the same module with gradients enabled (unsegmented, materialised delta)."""
+    from medical_image_classification_amd import medmamba as mm, ss2d_fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    m = mm.SS2D(d_model=48, d_state=16).to(dev)
+    x = torch.randn(1, 56, 56, 48, device=dev)
+    assert ss2d_fused._scan_segments(1 * 4 * 12, 98) >= 2
+    y_train = m(x.clone().requires_grad_())
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x)
+    y_train = y_train.detach()
+    assert float((y_eval - y_train).abs().max()) <= 1e-4 * float(y_train.abs().max())
+
+
+def test_graphed_forward_replays_the_eval_forward():
+    """infer.GraphedForward: the eval() forward of a small MedMamba captured in a HIP graph == the eager eval forward on the same and on NEW
+    inputs (the replay reads the static input buffer), shape changes are refused, the captured output buffer is reused."""
+    from medical_image_classification_amd import medmamba as mm
+    from medical_image_classification_amd.infer import GraphedForward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = mm.VSSM(depths=[1, 1, 1, 1], dims=[32, 64, 128, 256], num_classes=5).to(dev).eval()
+    x1, x2 = torch.randn(2, 3, 64, 64, device=dev), torch.randn(2, 3, 64, 64, device=dev)
+    fwd = GraphedForward(net, x1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        e1, e2 = net(x1).float(), net(x2).float()
+    g1 = fwd(x1).float().clone()
+    g2 = fwd(x2).float().clone()
+    tol = 2e-2 * float(e1.abs().max())                       # bf16 logits
+    assert float((g1 - e1).abs().max()) <= tol and float((g2 - e2).abs().max()) <= tol
+    assert float((g1 - g2).abs().max()) > 0.0                # the second replay really saw the new input
+    assert fwd(x1).data_ptr() == fwd(x2).data_ptr()
+    with pytest.raises(RuntimeError):
+        fwd(torch.randn(1, 3, 64, 64, device=dev))
+    with pytest.raises(RuntimeError):
+        GraphedForward(net, torch.randn(2, 3, 64, 64))
