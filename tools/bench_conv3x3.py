@@ -16,6 +16,8 @@ def cold(fn, n=6):
     ts.sort(); return ts[len(ts) // 2]
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 shapes = [(64, 128), (128, 64), (256, 32), (512, 16)] if len(sys.argv) > 2 and sys.argv[2] == "B" else [(48, 56), (96, 28), (192, 14), (384, 7)]
+if len(sys.argv) > 3:
+    shapes = [shapes[int(sys.argv[3])]]
 for C, Hh in shapes:
     x = torch.randn(bs, C, Hh, Hh, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, C, 3, 3, device=dev) * (9 * C) ** -0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
