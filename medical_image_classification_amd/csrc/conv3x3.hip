@@ -74,6 +74,9 @@ template <int CTRL> __device__ __forceinline__ float row_ror_add(float x) {
 #ifndef MS_CONV_ABL
 #define MS_CONV_ABL 0                    // timing ablations (wrong results): 1 no weight loads / 2 no halo loads / 3 neither after the first slice, 4 no products
 #endif
+#ifndef MS_CONV_PF
+#define MS_CONV_PF 1                     // slices of prefetch distance (register sets)
+#endif
 #ifndef MS_CONV_WAVES
 #define MS_CONV_WAVES 3                  // 50 KB of LDS: three workgroups per CU
 #endif
@@ -97,9 +100,9 @@ constexpr unsigned kOob = 0x80000000u;   // a byte offset beyond every buffer: t
 // the rocprofv3 counters showed the kernel bound by exactly that: matrix cores 15 % busy, LDS 23 %, waves issuing or parked.)
 // Every slice is multiplied with v_mfma_f32_16x16x32_bf16; a 16-channel tail (Ci = 48) has zeros in the upper half of both
 // operands (the K = 16 instruction occupies the matrix core for the same 16 cycles, so a separate path buys nothing).
-template <int NB, bool BNIN = false, bool STATS = false, bool BRED = false>
+template <int NB, bool BNIN = false, bool STATS = false, bool BRED = false, int PF = MS_CONV_PF>
 // (NB = 4, MedMamba-B's 64-channel blocks: 61 KB of LDS and 3 x 16 accumulator registers more -- two workgroups per CU is what fits)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB >= 4 ? 2 : MS_CONV_WAVES, NB >= 4 ? 2 : MS_CONV_WAVES)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB >= 4 || PF >= 2 ? 2 : MS_CONV_WAVES, NB >= 4 || PF >= 2 ? 2 : MS_CONV_WAVES)))
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
                     int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img, BnFoldDev bin, unsigned short *__restrict__ xhat,
                     BnFoldDev bout, BnBwdDev bred) {
@@ -108,9 +111,9 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
     constexpr int kNX = kRowsX * 4 / 256, kNW = kRowsW * 4 / 256;       // 16-byte pieces per thread: halo (3) and weights (7 / 9)
     static_assert(kRowsX * 4 % 256 == 0 && kRowsW * 4 % 256 == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned short sX[kRowsX * kXP];
-    __shared__ __attribute__((aligned(16))) unsigned short sW[9 * NB * 16 * kWP];
+    __shared__ __attribute__((aligned(16))) unsigned short sW[kRowsW * kWP];      // (whole passes: the staging writes need no guard)
     __shared__ __attribute__((aligned(16))) float sScale[BNIN ? kBnMaxC : 4], sShift[BNIN ? kBnMaxC : 4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the wave-uniform guards below become scalar branches)
     const int tile = blockIdx.x, img = tile / tiles_per_img, tt = tile - img * tiles_per_img;
     const int h0 = (tt / tiles_w) * kTH, w0 = (tt % tiles_w) * kTW;
     const int co0 = blockIdx.y * (NB * 16);
@@ -144,7 +147,8 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
         offw[i] = (row < 9 * NB * 16 && co0 + col < Co) ? (unsigned)((((co0 + col) * 9 + tap) * Ci + fq * 8) * 2) : kOob;
     }
     u32x4 rxa[kNX], rwa[kNW];
-    auto fetch = [&](int k0) {
+    u32x4 rxb[PF >= 2 ? kNX : 1], rwb[PF >= 2 ? kNW : 1];      // PF = 2: the second register set (two slices of prefetch distance)
+    auto fetch = [&](auto &rxa, auto &rwa, int k0) {
         const unsigned kill = (k0 + fq * 8 >= Ci) ? kOob : 0u;           // the upper pieces of a 16-channel tail slice
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
@@ -161,7 +165,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             rwa[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(offw[i] | kill), k0 * 2, 0);
         }
     };
-    auto put = [&](int k0) {
+    auto put = [&](const auto &rxa, const auto &rwa, int k0) {
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
             u32x4 v = rxa[i];
@@ -182,9 +186,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
             *reinterpret_cast<u32x4 *>(sX + ((wv + 4 * i) * 16 + fr) * kXP + swz(fr, fq)) = v;
         }
 #pragma unroll
-        for (int i = 0; i < kNW; ++i)
-            if ((wv + 4 * i) * 16 < 9 * NB * 16)                   // (wave-uniform: the last pass of NB = 3 has one group of rows past the end)
-                *reinterpret_cast<u32x4 *>(sW + ((wv + 4 * i) * 16 + fr) * kWP + swz(fr, fq)) = rwa[i];
+        for (int i = 0; i < kNW; ++i) *reinterpret_cast<u32x4 *>(sW + ((wv + 4 * i) * 16 + fr) * kWP + swz(fr, fq)) = rwa[i];
     };
     // One slice's products, fragment reads one tap ahead of the MFMAs that use them.  Taps run column-major (dx outer): the wave's two
     // output rows need halo rows 0..3 of a column offset, two of them per tap, so every tap after the first of a column reads ONE new
@@ -220,7 +222,11 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
         }
     };
     MS_STAMP(0);
-    fetch(0);
+    fetch(rxa, rwa, 0);
+    // PF = 2 (dispatched for Ci % 64 == 0 only: an even number of slices): every fetch and every slice below is unconditional -- a fetch
+    // past Ci is all out-of-range offsets -- so that the compiler can COUNT the loads in flight: with a conditional fetch it has to
+    // assume the younger set absent and waits for all of it (s_waitcnt vmcnt(9..0) instead of vmcnt(19..10)) before the first LDS write.
+    if constexpr (PF >= 2) { __builtin_amdgcn_sched_barrier(0); fetch(rxb, rwb, kKS); }                    // (in this order: the first put waits for set a only)
     MS_STAMP(1);
     if constexpr (BNIN) {
         // scale / shift of every input channel from the replica rows (the first slice's loads are in flight meanwhile)
@@ -242,23 +248,29 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ x, const unsigned short *
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && bin.nbt) *bin.nbt += 1;
         // (a 16-channel tail reads the tables up to the next multiple of 32: the entries past Ci are never used -- `ok` is false there)
     }
-#if MS_CONV_ABL == 6
-    for (int k0 = 0; k0 < kKS; k0 += kKS) {
-#else
-    for (int k0 = 0; k0 < Ci; k0 += kKS) {
-#endif
-        __syncthreads();                                        // the previous slice's fragments have been read (first trip: the tables are written)
+    // one slice: barrier (the previous slice's fragments have been read; first trip: the tables are written), registers -> LDS, barrier,
+    // the loads of the slice PF ahead into the freed register set, the products
+    auto slice = [&](auto &rx, auto &rw, int k0) {
+        __syncthreads();
         MS_STAMP(2 + (k0 / kKS) * 4);
-        put(k0);
+        put(rx, rw, k0);
         MS_STAMP(3 + (k0 / kKS) * 4);
         __syncthreads();
         MS_STAMP(4 + (k0 / kKS) * 4);
-        if (k0 + kKS < Ci) fetch(k0 + kKS);                     // in flight during the products below
+        if (PF >= 2 || k0 + PF * kKS < Ci) fetch(rx, rw, k0 + PF * kKS);
 #if MS_CONV_ABL == 4
         if (k0 == 0)
 #endif
         mac();
         MS_STAMP(5 + (k0 / kKS) * 4);
+    };
+#if MS_CONV_ABL == 6
+    for (int k0 = 0; k0 < kKS; k0 += PF * kKS) {
+#else
+    for (int k0 = 0; k0 < Ci; k0 += PF * kKS) {
+#endif
+        slice(rxa, rwa, k0);
+        if constexpr (PF >= 2) slice(rxb, rwb, k0 + kKS);
     }
     // D = B^T-major product: row index (4 * fq + r) = output channel within the tile, column fr = pixel
 #pragma unroll

@@ -1,5 +1,5 @@
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-for a in 0 w2 w4; do
+for a in ${VARS:-0 pf2}; do
   L=$R/build/variants/libmedscan_conv$a.so; [ $a == 0 ] && L=$R/medical_image_classification_amd/libmedscan.so
   rm -rf /tmp/cabl; MEDSCAN_LIBRARY=$L rocprofv3 --kernel-trace -d /tmp/cabl --output-format csv -- python3 $R/tools/bench_conv3x3.py 64 T > /dev/null 2>&1
   python3 - $a <<'PY'
