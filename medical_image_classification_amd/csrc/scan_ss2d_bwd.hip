@@ -21,9 +21,6 @@
 #ifndef MS_BWD_FULLPATH
 #define MS_BWD_FULLPATH 0
 #endif
-#ifndef MS_BWD_LDSPF
-#define MS_BWD_LDSPF 0
-#endif
 #ifndef MS_BWD_W3_DEFAULT
 #define MS_BWD_W3_DEFAULT false
 #endif
@@ -33,7 +30,7 @@ namespace {
 
 constexpr int kNs = 16;                 // d_state
 constexpr int kCWb = 8, kNWb = 4, kNTb = 64 * kNWb, kNBb = kCL / 4;
-constexpr int kRPb = kNs + 4;           // [position][state] B / C tile pitch (floats)
+constexpr int kSGb = kNs / 2;           // state pairs per position (the sweeps' lanes hold two states each)
 constexpr int kRowPb = kCL + 4;         // dB / dC tile: [state][position] row pitch
 constexpr int kDCb = kNs * kRowPb + 2;  // dC tile 2 banks past the dB tile (the combine reads both in one instruction)
 constexpr int kWSb = kDCb + kNs * kRowPb;
@@ -58,15 +55,18 @@ __global__ void __launch_bounds__(kNTb) __attribute__((amdgpu_waves_per_eu(W3 ? 
 ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
     constexpr int CW = kCWb, NB = kNBb, NPAR = W3 ? 1 : 2;
     const MsScanParams &p = q.f;
-    __shared__ __attribute__((aligned(16))) float sBC[2][2][kCL * kRPb];           // [chunk parity][B | C][position][state]
-    __shared__ __attribute__((aligned(16))) v2f sP1_[kNWb][kCL * CW];              // {delta', u}
-    __shared__ __attribute__((aligned(16))) v2f sP2_[kNWb][kCL * CW];              // {dout, delta' * u}
+    // The sweeps' LDS operands are laid out so that a lane needs ONE 16-byte read per array and position: {delta', u, dout, delta' u} of its
+    // channel, and {B, C} of its state pair.  (Until round 3 they were four 8-byte arrays; the compiler paired the reads of neighbouring
+    // positions into ds_read2_b64, which occupies the LDS for 8 cycles against 4 for a ds_read_b128 of the same 16 bytes -- the kernel's LDS
+    // pipe was 49 % busy; measured with the reads re-pointed, values wrong: 4.67 -> 4.46 ms per step.)
+    __shared__ __attribute__((aligned(16))) float4 sBCq[2][kCL * kSGb];            // [chunk parity][position][state pair] = {B0, B1, C0, C1}
+    __shared__ __attribute__((aligned(16))) float4 sP_[kNWb][kCL * CW];            // [position][channel] = {delta', u, dout, delta' * u}
     __shared__ __attribute__((aligned(16))) float sOut_[NPAR][kNWb][2][kCL * CW];  // [parity][wave][du | ddelta'][position][channel]
     __shared__ float sdBC_[NPAR][kNWb][kWSb];                                       // [parity][wave] dB | dC of the wave's channels
     __shared__ int stab[4][kCL];                                                    // pixel positions of 4 chunks (ring)
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    v2f *sP1 = sP1_[wv], *sP2 = sP2_[wv];
+    float4 *sP = sP_[wv];
     // sweep domain: lane = (state group sg, channel c); I/O domain: lane = (position pl, channel quad)
     const int c = lane & 7, sg = lane >> 3;
     const int pl = lane >> 1, q4 = (lane & 1) * 4;
@@ -197,7 +197,7 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
         const int par = ch & 1, len = min(kCL, L - ch * kCL);
         const bool have_prev = ch + 1 < n_chunks;
-        float *sB = sBC[par][0], *sC = sBC[par][1];
+        const float4 *sBCl = sBCq[par] + sg;                          // this lane's state pair inside a position row
         const int po = W3 ? 0 : par, pp = W3 ? 0 : par ^ 1;        // tile parity of this chunk's results / of the previous chunk's
         float *su = sOut_[po][wv][0], *sgd = sOut_[po][wv][1];
         float *sdB = sdBC_[po][wv], *sdC = sdBC_[po][wv] + kDCb;
@@ -221,12 +221,13 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                 dDk[j] = fmaf(gg[j], uu[j], dDk[j]);
             }
             sig_cur = make_float4(sg4[0], sg4[1], sg4[2], sg4[3]);
-            float *d1 = reinterpret_cast<float *>(sP1 + pl * CW + q4), *d2 = reinterpret_cast<float *>(sP2 + pl * CW + q4);
-            st4b(d1, make_float4(dl[0], uu[0], dl[1], uu[1])); st4b(d1 + 4, make_float4(dl[2], uu[2], dl[3], uu[3]));
-            st4b(d2, make_float4(gg[0], dl[0] * uu[0], gg[1], dl[1] * uu[1]));
-            st4b(d2 + 4, make_float4(gg[2], dl[2] * uu[2], gg[3], dl[3] * uu[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sP[pl * CW + q4 + j] = make_float4(dl[j], uu[j], gg[j], dl[j] * uu[j]);
             const float4 bc = (bc_r >> 2) < len ? rBC : make_float4(0.f, 0.f, 0.f, 0.f);
-            st4b(sBC[par][bc_is_c] + (bc_r >> 2) * kRPb + 4 * (bc_r & 3), bc);
+            // this thread's four states are two state pairs: the B thread fills the first half of their entries, the C thread the second
+            float *bq = reinterpret_cast<float *>(sBCq[par] + (bc_r >> 2) * kSGb + 2 * (bc_r & 3)) + 2 * bc_is_c;
+            *reinterpret_cast<v2f *>(bq) = (v2f){bc.x, bc.y};
+            *reinterpret_cast<v2f *>(bq + 4) = (v2f){bc.z, bc.w};
         }
         v2f hp = ch > 0 ? (v2f){rx0, rx1} : (v2f){0.0f, 0.0f};
         pos_cur = pos_next;
@@ -258,7 +259,6 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
         auto sweeps = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
         v2f ap[W3 ? 1 : kCL], ckp[NB];
-        const float *sBl = sB + sg * 2, *sCl = sC + sg * 2;          // this lane's state pair inside a position row
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             if constexpr (FULL && MS_BWD_FULLPATH == 1) __builtin_amdgcn_sched_barrier(0);
@@ -267,12 +267,11 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                 for (int l = kb * 4; l < kb * 4 + 4; ++l) {
                     if ((l & 3) == 0) ckp[l >> 2] = hp;
 #ifdef MS_ABL_NOLDS
-                    const v2f p1 = sP1[c], p2 = sP2[c];
-                    const v2f Bp = *reinterpret_cast<const v2f *>(sBl);
+                    const float4 pq = sP[c], bcq = sBCl[0];
 #else
-                    const v2f p1 = sP1[l * CW + c], p2 = sP2[l * CW + c];      // {delta', u}, {dout, delta' u}
-                    const v2f Bp = *reinterpret_cast<const v2f *>(sBl + l * kRPb);
+                    const float4 pq = sP[l * CW + c], bcq = sBCl[l * kSGb];
 #endif
+                    const v2f p1 = {pq.x, pq.y}, p2 = {pq.z, pq.w}, Bp = {bcq.x, bcq.y};     // {delta', u}, {dout, delta' u}, B pair
 #ifdef MS_ABL_NOEXP
                     const v2f a = pk_fma((v2f){p1.x, p1.x}, A2p, (v2f){1.0f, 1.0f});
 #else
@@ -294,24 +293,6 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
             }
         }
         if constexpr (W3) __syncthreads();     // every wave has read the previous chunk's dB / dC tiles: the reverse sweep may overwrite them
-#if MS_BWD_LDSPF >= 1
-        // the LDS operands of a reverse batch are read ONE BATCH AHEAD (the compiler places a batch's reads at the top of its block and
-        // waits for them at once: three exposed LDS round trips per batch in the listing); the first batch's are read here
-        v2f nB[4], nP2[4];
-#if MS_BWD_LDSPF >= 2
-        v2f nC[4], nP1[4];
-#endif
-        {
-            const int lbf = FULL ? kCL - 4 : ((len - 1) >> 2) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                nB[j] = *reinterpret_cast<const v2f *>(sBl + (lbf + j) * kRPb); nP2[j] = sP2[(lbf + j) * CW + c];
-#if MS_BWD_LDSPF >= 2
-                nC[j] = *reinterpret_cast<const v2f *>(sCl + (lbf + j) * kRPb); nP1[j] = sP1[(lbf + j) * CW + c];
-#endif
-            }
-        }
-#endif
 #pragma unroll
         for (int kb = NB - 1; kb >= 0; --kb) {
             const int lb = kb * 4;
@@ -320,34 +301,13 @@ ss2d_bwd_kernel(const MsScanBwdParams q, const int n_chunks) {
                 v2f Bp[4], Cp[4], bu[4], hv[4], p1[4], p2[4], aj[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-#if MS_BWD_LDSPF >= 1
-                    Bp[j] = nB[j]; p2[j] = nP2[j];
-#elif defined(MS_ABL_NOLDS)
-                    Bp[j] = *reinterpret_cast<const v2f *>(sBl); p2[j] = sP2[c];
+#ifdef MS_ABL_NOLDS
+                    const float4 pq = sP[c], bcq = sBCl[0];
 #else
-                    Bp[j] = *reinterpret_cast<const v2f *>(sBl + (lb + j) * kRPb);
-                    p2[j] = sP2[(lb + j) * CW + c];
+                    const float4 pq = sP[(lb + j) * CW + c], bcq = sBCl[(lb + j) * kSGb];
 #endif
-#if MS_BWD_LDSPF >= 2
-                    Cp[j] = nC[j]; p1[j] = nP1[j];
-#elif defined(MS_ABL_NOLDS)
-                    Cp[j] = *reinterpret_cast<const v2f *>(sCl); p1[j] = sP1[c];
-#else
-                    Cp[j] = *reinterpret_cast<const v2f *>(sCl + (lb + j) * kRPb);
-                    p1[j] = sP1[(lb + j) * CW + c];
-#endif
+                    p1[j] = (v2f){pq.x, pq.y}; p2[j] = (v2f){pq.z, pq.w}; Bp[j] = (v2f){bcq.x, bcq.y}; Cp[j] = (v2f){bcq.z, bcq.w};
                 }
-#if MS_BWD_LDSPF >= 1
-                if (kb > 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        nB[j] = *reinterpret_cast<const v2f *>(sBl + (lb - 4 + j) * kRPb); nP2[j] = sP2[(lb - 4 + j) * CW + c];
-#if MS_BWD_LDSPF >= 2
-                        nC[j] = *reinterpret_cast<const v2f *>(sCl + (lb - 4 + j) * kRPb); nP1[j] = sP1[(lb - 4 + j) * CW + c];
-#endif
-                    }
-                }
-#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if constexpr (W3) aj[j] = exp2_pk((v2f){p1[j].x, p1[j].x} * A2p); else aj[j] = ap[lb + j];
