@@ -8,6 +8,7 @@
 //        all 9 taps and the workgroup's output channels
 //   MFMA: v_mfma_f32_16x16x16_bf16 -- K = 16 input channels per instruction divides every channel count of the model
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "medscan.h"
 
 namespace ms {
@@ -500,11 +501,14 @@ template <int kGC>
 __global__ void __launch_bounds__(256, kGC == 64 ? 1 : 2)
 conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, float *__restrict__ part,
                      int H, int W, int Ci, int Co, int tiles_w, int tiles_per_img, int n_tiles, int nci) {
-    constexpr int kGP = kGC + 8;                     // LDS pixel pitch (bf16)
+    constexpr int kGP = 80;                          // LDS pixel pitch (bf16): 160 B = 32 B x 5 -- a ds_read_b64_tr_b16 serves 32 lanes = 8 pixel rows x 32 B at once,
+                                                     // and rows 160 B apart fall into 8 different 32-byte bank groups (112 / 144 B: two of the 8 overlap; 50 % of the
+                                                     // kernel's LDS cycles were conflicts)
+    static_assert(kGC <= 64, "pixel pitch");
     constexpr int NT = kGC / 16, kCols = 9 * NT;     // channel tiles per side; product columns (tap, ci tile)
     __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kGP];      // x halo tile, kGC input channels
     __shared__ __attribute__((aligned(16))) unsigned short sG[kTH * kTW * kGP];      // dy tile, kGC output channels
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cob = blockIdx.y / nci, cib = blockIdx.y % nci;
     const int co0 = cob * kGC, ci0 = cib * kGC;
     // this wave's product columns: col = tap * NT + ci tile, col % 4 == wv
@@ -555,20 +559,26 @@ conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short 
         }
         __syncthreads();
         if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        // one k-step = the 32 pixels of TWO image rows (v_mfma_f32_16x16x32_bf16: the K = 16 form occupies the matrix core for the same 16
+        // cycles): a lane's 8 k-values are pixels 4 fq .. 4 fq + 3 of row r and of row r + 1 -- the same assignment on both operands
+        auto frag2 = [&](const unsigned short *s_row, int row_pitch) {
+            const bf16x4 lo = tr_frag(s_row, kGP, lane), hi = tr_frag(s_row + row_pitch * kGP, kGP, lane);
+            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
 #pragma unroll 2
-        for (int r = 0; r < kTH; ++r) {
-            bf16x4 ga[NT];
+        for (int r = 0; r < kTH; r += 2) {
+            bf16x8 ga[NT];
 #pragma unroll
-            for (int a = 0; a < NT; ++a) ga[a] = tr_frag(sG + (r * kTW) * kGP + a * 16, kGP, lane);
+            for (int a = 0; a < NT; ++a) ga[a] = frag2(sG + (r * kTW) * kGP + a * 16, kTW);
 #pragma unroll
             for (int j = 0; j < kMaxCols; ++j) {
                 const int col = wv + 4 * j;                       // compile-time j, wave-uniform col
                 if (col < kCols) {
                     const int tap = col / NT, ct = col - tap * NT;
                     const int dyy = tap / 3, dxx = tap - dyy * 3;
-                    const bf16x4 xb = tr_frag(sX + ((r + dyy) * kHW + dxx) * kGP + ct * 16, kGP, lane);
+                    const bf16x8 xb = frag2(sX + ((r + dyy) * kHW + dxx) * kGP + ct * 16, kHW);
 #pragma unroll
-                    for (int a = 0; a < NT; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[a], xb, acc[a][j], 0, 0, 0);
+                    for (int a = 0; a < NT; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a], xb, acc[a][j], 0, 0, 0);
                 }
             }
         }
@@ -633,7 +643,8 @@ conv3x3_wgrad_finalize_kernel(const float *__restrict__ part, float *__restrict_
 }
 
 static int wgrad_workers(int n_tiles, int nblk) {
-    int wk = (512 + nblk - 1) / nblk;                       // about two workgroups per CU in total (256: main 55 + finalize 18 us; 512: 35 + 34)
+    static const int total = [] { const char *e = getenv("MEDSCAN_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int wk = (total + nblk - 1) / nblk;                     // about two workgroups per CU in total (256: main 55 + finalize 18 us; 512: 35 + 34)
     if (wk > n_tiles) wk = n_tiles;
     return wk < 1 ? 1 : wk;
 }
