@@ -506,8 +506,11 @@ conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short 
                                                      // kernel's LDS cycles were conflicts)
     static_assert(kGC <= 64, "pixel pitch");
     constexpr int NT = kGC / 16, kCols = 9 * NT;     // channel tiles per side; product columns (tap, ci tile)
-    __shared__ __attribute__((aligned(16))) unsigned short sX[kHH * kHW * kGP];      // x halo tile, kGC input channels
-    __shared__ __attribute__((aligned(16))) unsigned short sG[kTH * kTW * kGP];      // dy tile, kGC output channels
+    constexpr int kPC = kGC / 8;                                        // 16-byte pieces per pixel
+    constexpr int kNX = (kHH * kHW * kPC + 255) / 256, kNG = (kTH * kTW * kPC + 255) / 256;      // 16-byte loads per thread and tile: halo, dy
+    constexpr int kPixX = (kNX * 256 + kPC - 1) / kPC, kPixG = (kNG * 256 + kPC - 1) / kPC;      // LDS pixels incl. the last pass's overhang (unguarded writes)
+    __shared__ __attribute__((aligned(16))) unsigned short sX[kPixX * kGP];          // x halo tile, kGC input channels
+    __shared__ __attribute__((aligned(16))) unsigned short sG[kPixG * kGP];          // dy tile, kGC output channels
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cob = blockIdx.y / nci, cib = blockIdx.y % nci;
     const int co0 = cob * kGC, ci0 = cib * kGC;
@@ -519,44 +522,55 @@ conv3x3_wgrad_kernel(const unsigned short *__restrict__ x, const unsigned short 
 #pragma unroll
         for (int j = 0; j < kMaxCols; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging through registers, one tile ahead: the next tile's 16-byte loads (<= 8 per thread) are in flight while this tile
-    // is multiplied (same scheme as the forward kernel above)
-    constexpr int kPC = kGC / 8;                                        // 16-byte pieces per pixel
-    constexpr int kNX = (kHH * kHW * kPC + 255) / 256, kNG = (kTH * kTW * kPC + 255) / 256;
-    uint4 rx[kNX], rg[kNG];
+    // staging through registers, one tile ahead: the next tile's 16-byte loads (<= 10 per thread) are in flight while this tile is
+    // multiplied.  Raw buffer loads; what does not depend on the tile -- a piece's position inside the tile, its byte offset relative to
+    // the tile's first pixel, its LDS address -- is worked out once per thread, per tile only the scalar tile origin and the edge
+    // tests are left (the first version redid the index arithmetic of every load for every tile: ~400 vector instructions per tile and
+    // wave beside 84 MFMAs).
+    const int batch = n_tiles / tiles_per_img;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(x), 0, (int)((int64_t)batch * H * W * Ci * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(dy), 0, (int)((int64_t)batch * H * W * Co * 2), 0x00020000);
+    int relx[kNX], hwx[kNX], ldx[kNX], relg[kNG], hwg[kNG], ldg[kNG];      // hw*: (row << 16 | column) inside the tile, -1 = not a piece of the tile
+#pragma unroll
+    for (int i = 0; i < kNX; ++i) {
+        const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC, ph = pix / kHW - 1, pw = pix % kHW - 1;
+        relx[i] = ((ph * W + pw) * Ci + ci0 + pc * 8) * 2;
+        hwx[i] = (idx < kHH * kHW * kPC && ci0 + pc * 8 < Ci) ? ((ph + 1) << 16) | (pw + 1) : -1;
+        ldx[i] = pix * kGP + pc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < kNG; ++i) {
+        const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC, ph = pix / kTW, pw = pix % kTW;
+        relg[i] = ((ph * W + pw) * Co + co0 + pc * 8) * 2;
+        hwg[i] = (idx < kTH * kTW * kPC && co0 + pc * 8 < Co) ? (ph << 16) | pw : -1;
+        ldg[i] = pix * kGP + pc * 8;
+    }
+    u32x4 rx[kNX], rg[kNG];
     auto fetch = [&](int tile) {
         const int img = tile / tiles_per_img, tt = tile - img * tiles_per_img;
         const int h0 = (tt / tiles_w) * kTH, w0 = (tt % tiles_w) * kTW;
+        const int pix0 = (img * H + h0) * W + w0;                       // the tile's first output pixel
+        const int bx = pix0 * Ci * 2, bg = pix0 * Co * 2;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
-            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
-            const int ph = pix / kHW, hh = h0 - 1 + ph, ww = w0 - 1 + pix - ph * kHW;
-            rx[i] = make_uint4(0, 0, 0, 0);
-            if (idx < kHH * kHW * kPC && hh >= 0 && hh < H && ww >= 0 && ww < W && ci0 + pc * 8 < Ci)
-                rx[i] = *reinterpret_cast<const uint4 *>(x + (((int64_t)img * H + hh) * W + ww) * Ci + ci0 + pc * 8);
+            const int hh = h0 - 1 + (hwx[i] >> 16), ww = w0 - 1 + (hwx[i] & 0xFFFF);
+            const bool ok = hwx[i] >= 0 && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? bx + relx[i] : (int)kOob, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < kNG; ++i) {
-            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
-            const int hh = h0 + pix / kTW, ww = w0 + pix % kTW;
-            rg[i] = make_uint4(0, 0, 0, 0);
-            if (idx < kTH * kTW * kPC && hh < H && ww < W && co0 + pc * 8 < Co)
-                rg[i] = *reinterpret_cast<const uint4 *>(dy + (((int64_t)img * H + hh) * W + ww) * Co + co0 + pc * 8);
+            const int hh = h0 + (hwg[i] >> 16), ww = w0 + (hwg[i] & 0xFFFF);
+            const bool ok = hwg[i] >= 0 && hh < H && ww < W;
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsg, ok ? bg + relg[i] : (int)kOob, 0, 0);
         }
     };
     if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < kNX; ++i) {
-            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
-            if (idx < kHH * kHW * kPC) *reinterpret_cast<uint4 *>(sX + pix * kGP + pc * 8) = rx[i];
-        }
+        for (int i = 0; i < kNX; ++i) *reinterpret_cast<u32x4 *>(sX + ldx[i]) = rx[i];
 #pragma unroll
-        for (int i = 0; i < kNG; ++i) {
-            const int idx = tid + i * 256, pix = idx / kPC, pc = idx - pix * kPC;
-            if (idx < kTH * kTW * kPC) *reinterpret_cast<uint4 *>(sG + pix * kGP + pc * 8) = rg[i];
-        }
+        for (int i = 0; i < kNG; ++i) *reinterpret_cast<u32x4 *>(sG + ldg[i]) = rg[i];
         __syncthreads();
         if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
         // one k-step = the 32 pixels of TWO image rows (v_mfma_f32_16x16x32_bf16: the K = 16 form occupies the matrix core for the same 16
@@ -662,6 +676,7 @@ int conv3x3_wgrad_dispatch(const void *x, const void *dy, float *dW, float *scra
     if (!x || !dy || !dW || !scratch) return MS_ERR_NULL;
     if (batch <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 8 != 0 || Co % 8 != 0) return MS_ERR_SHAPE;
     if (scratch_floats < conv3x3_wgrad_scratch_floats(batch, H, W, Ci, Co)) return MS_ERR_SHAPE;
+    if ((int64_t)batch * H * W * (Ci > Co ? Ci : Co) >= (1ll << 30)) return MS_ERR_UNSUPPORTED;          // 32-bit byte offsets into x / dy
     const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH;
     const int tiles_per_img = tiles_w * tiles_h, n_tiles = batch * tiles_per_img;
     const int gc = wgrad_gc(Ci, Co);
