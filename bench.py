@@ -39,11 +39,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 # (tools/kernel_mix.py): per 32-position chunk of an 8-channel x 16-state wave (64 lanes x 64 elements).
 VALU_CYCLES_PER_INSTR, N_SIMD, MAX_CLOCK_HZ = 4.3, 1024, 2.4e9
 # scan_bwd: VALU wave-instructions per state element of the software-pipelined SS2D backward (round 3, scan_ss2d_bwd.hip), from the
-# rocprofv3 counters of the bench step itself (profiles/r03_scan_pmc_summary.json: SQ_INSTS_VALU 154.4 M per launch x 64 lanes over
-# 524 M state elements per launch; 175.2 M = 21.4 before this round's instruction diet); round 2's kernel: 24.3 (1555 per 32-position
+# rocprofv3 counters of the bench step itself (profiles/r03_scan_pmc_summary.json: SQ_INSTS_VALU 161.3 M per launch x 64 lanes over
+# 524 M state elements per launch -- 154.4 M before the 16-byte LDS operand layout, which traded 7 M register moves for half the LDS
+# cycles and is 2.5 % faster; 175.2 M = 21.4 before this round's instruction diet); round 2's kernel: 24.3 (1555 per 32-position
 # chunk of an 8-channel wave).  scan_fwd: 43.6 M x 64 / 524 M.  NOTE: the kernels are bound by the issue of ALL
 # instruction kinds (~5.5 cycles each across a SIMD's waves), so this vector-only floor understates what the shipped code needs.
-VALU_INSTR_PER_STATE_ELEM = {"scan_bwd": 18.85, "scan_fwd": 5.33}
+VALU_INSTR_PER_STATE_ELEM = {"scan_bwd": 19.70, "scan_fwd": 5.33}
 
 def parse():
     ap = argparse.ArgumentParser()
