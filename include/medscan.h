@@ -449,7 +449,9 @@ int ms_adam_multi(const MsAdamDesc *desc, const int32_t *blocks, int n_blocks, c
  * stride 1, padding 1, groups 1, no bias; x (batch, H, W, Ci), y (batch, H, W, Co) bf16 channels_last memory; w bf16 in
  * (Co, 3, 3, Ci) memory order (= a channels_last copy of the (Co, Ci, 3, 3) weight, what ms_cast_bf16_multi writes); fp32
  * accumulation on the matrix cores.  Ci, Co multiples of 16.  The input gradient is the same call on dy with the flipped,
- * transposed weight w'[ci][8 - tap][co]. */
+ * transposed weight w'[ci][8 - tap][co].  The kernels address with 32-bit byte offsets (raw buffer loads): an image (H * W * Ci elements) or
+ * the weight (Co * 9 * Ci) of 2^30 elements or more returns MS_ERR_UNSUPPORTED; for the weight gradient the limit applies to the whole
+ * activation tensor (batch * H * W * max(Ci, Co)). */
 int ms_conv3x3_nhwc_bf16(const void *x, const void *w, void *y, int batch, int H, int W, int Ci, int Co, void *stream);
 /* Its weight gradient: dW (Co, Ci, 3, 3) fp32 contiguous is WRITTEN = sum over pixels of dy[p, co] * x[p + tap, ci] (x, dy bf16
  * channels_last memory; Ci, Co multiples of 8).  `scratch`: ms_conv3x3_wgrad_scratch_floats(..) floats of workspace (the persistent

@@ -66,6 +66,12 @@ def test_null_and_shape_errors_without_gpu(lib):
     assert lib.ms_dwconv3x3_silu_fwd(None, None, None, None, 1, 1, 1, 1, None) == -1
     assert lib.ms_adam_multi(None, None, 1, None, 1, 1e-3, 1.0, 0.1, 0.999, 1e-3, 1e-8, None) == -1
     assert lib.ms_adam_multi(None, None, 1, None, 449, 1e-3, 1.0, 0.1, 0.999, 1e-3, 1e-8, None) == -2      # more tensors than one launch carries
+    # the convolutions address with 32-bit byte offsets: sizes beyond that are refused before anything is launched (include/medscan.h)
+    dummy = ctypes.c_void_p(64)
+    assert lib.ms_conv3x3_nhwc_bf16(dummy, dummy, dummy, 1, 32768, 32768, 16, 16, None) == -6
+    assert lib.ms_conv3x3_nhwc_bf16(dummy, dummy, dummy, 1, 8, 8, 24, 16, None) == -2                           # Ci not a multiple of 16
+    assert lib.ms_conv3x3_wgrad(dummy, dummy, ctypes.cast(dummy, ctypes.POINTER(ctypes.c_float)), ctypes.cast(dummy, ctypes.POINTER(ctypes.c_float)),
+                                1 << 40, 4096, 1024, 1024, 16, 16, None) == -6
 
 
 def test_cpu_tensors_fail_loudly():
