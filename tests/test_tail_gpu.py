@@ -128,6 +128,29 @@ def test_direct_conv3x3_forward_and_input_gradient_vs_fp32(cfg):
     np.testing.assert_allclose(dw.cpu().numpy(), dwr.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(dwr.abs().max()), err_msg="dW")
 
 
+@pytest.mark.parametrize("cfg", [(2, 80, 48, 13, 19), (1, 32, 112, 9, 33), (3, 16, 64, 8, 16), (1, 144, 96, 20, 7), (2, 48, 80, 1, 40)])
+def test_direct_conv3x3_with_unequal_channel_counts(cfg):
+    """The same three kernels with Ci != Co -- partial output-channel blocks (Co not a multiple of 48), 16-channel tail slices behind full
+    ones (Ci = 80, 144), one-slice inputs (Ci = 16, 32), ragged tiles: the model only has square convolutions, the entry points do not."""
+    from medical_image_classification_amd.block_ops import _conv3x3_direct, _conv3x3_wgrad
+    B, Ci, Co, H, W = cfg
+    torch.manual_seed(37)
+    w = (torch.randn(Co, Ci, 3, 3, device=dev()) * (9 * Ci) ** -0.5).to(torch.bfloat16)
+    x = torch.randn(B, Ci, H, W, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, Co, H, W, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = _conv3x3_direct(x, w.contiguous(memory_format=torch.channels_last))                       # (Co, 3, 3, Ci) memory
+    dx = _conv3x3_direct(g, w.flip(2, 3).permute(1, 2, 3, 0).contiguous())                        # (Ci, 3, 3, Co) memory, taps flipped
+    assert y.shape == (B, Co, H, W) and dx.shape == (B, Ci, H, W)
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    yr = F.conv2d(xr, wr, padding=1)
+    dxr, dwr = torch.autograd.grad(yr, (xr, wr), g.float())
+    for got, want, name in ((y, yr, "y"), (dx, dxr, "dx")):
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-2, atol=6e-3 * float(want.abs().max()),
+                                   err_msg=name)
+    dw = _conv3x3_wgrad(x, g, w.shape)
+    np.testing.assert_allclose(dw.cpu().numpy(), dwr.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(dwr.abs().max()), err_msg="dW")
+
+
 @pytest.mark.parametrize("cfg", [(2, 48, 56, 56), (3, 96, 9, 7), (64, 384, 7, 7)])
 @pytest.mark.parametrize("premasked", [False, True])
 def test_conv1x1_relu_on_the_mfma_gemm(cfg, premasked):
