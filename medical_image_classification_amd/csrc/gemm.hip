@@ -69,14 +69,20 @@ struct TileStage {
     }
     // the MFMA operand fragment of the tile's rows [16 t, 16 t + 16), k-step ks: lane (fr = lane & 15, fq = lane >> 4) gets
     // op(X)[16 t + fr][32 ks + 8 fq + j], j = 0..7
+    // ALTK (both operands transposed -- the weight-gradient form): a lane's 8 k-values are rows 4 fq .. 4 fq + 3 and 16 + 4 fq .. of the
+    // k-step instead of 8 fq .. 8 fq + 7.  Any assignment works as long as both operands use the same one; with this one the 32 lanes a
+    // ds_read_b64_tr_b16 serves together read 8 CONSECUTIVE k-rows, which the pitch spreads over all banks -- the default assignment
+    // (forced by the plain operand's contiguous 8 k when only one side is transposed) has rows r and r + 8 in one pass, and those
+    // collide at every pitch that keeps rows 16-byte aligned (a third of these instantiations' LDS cycles were conflicts).
+    template <bool ALTK = false>
     static __device__ __forceinline__ bf16x8 frag(const unsigned short *s, int t, int ks, int lane) {
         const int fr = lane & 15, fq = lane >> 4;
         if (!TR) return *reinterpret_cast<const bf16x8 *>(s + (t * 16 + fr) * kPitch + ks * 32 + fq * 8);
         // lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of the 4 x 16 block; it receives column (lane & 15)
-        const unsigned short *b = s + (ks * 32 + fq * 8 + (fr >> 2)) * kPT + t * 16 + 4 * (fr & 3);
+        const unsigned short *b = s + (ks * 32 + fq * (ALTK ? 4 : 8) + (fr >> 2)) * kPT + t * 16 + 4 * (fr & 3);
         typedef bf16x4 __attribute__((address_space(3))) *lds_p;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + 4 * kPT));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + (ALTK ? 16 : 4) * kPT));
         return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 };
@@ -154,7 +160,7 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
         for (int ks = 0; ks < kBK / 32; ++ks) {
             bf16x8 fa[MT];
 #pragma unroll
-            for (int b = 0; b < MT; ++b) fa[b] = TA::frag(sA, w * MT + b, ks, lane);
+            for (int b = 0; b < MT; ++b) fa[b] = TA::template frag<ATR && BTR>(sA, w * MT + b, ks, lane);
             if constexpr (CMODE == 2) {
                 if (row_sums) {
 #pragma unroll
@@ -163,7 +169,7 @@ gemm_bf16_kernel(const void *A, const void *B, void *C, int M, int N, int K, int
             }
 #pragma unroll
             for (int a = 0; a < TNT; ++a) {
-                const bf16x8 fb = TB::frag(sB, a, ks, lane);
+                const bf16x8 fb = TB::template frag<ATR && BTR>(sB, a, ks, lane);
 #pragma unroll
                 for (int b = 0; b < MT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[b], acc[a][b], 0, 0, 0);
