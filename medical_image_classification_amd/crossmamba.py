@@ -112,6 +112,22 @@ class PatchEmbed2D(_PatchEmbedNCHW):
         return super().forward(x.permute(0, 3, 1, 2))
 
 
+def _conv1x1_last(conv, x):
+    """`conv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)` for a 1 x 1 / stride 1 `nn.Conv2d` on channel-last tokens (the two bridges and the
+    output head, CrossMamba_fusion_2b2.py:1158-1160,1283-1285): a Linear over the last dimension, which is how it runs here.  Handed to
+    the convolution library as a permuted view, the three of them took MIOpen's `naive_conv_*_nonpacked_*` / a grouped-convolution
+    weight-gradient kernel at 175-204 ms PER CALL -- 59 % of the kernel time of the fusion step (profiles/r03_vfefm_kernels_before.txt)."""
+    if not (type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[-1] == conv.in_channels):
+        return conv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    if conv.out_channels % 8 == 0 and conv.in_channels % 8 == 0 and x.is_cuda:
+        from .ss2d_ops import linear_splitk            # this package's GEMMs (as cnn_mamba.proj); the bias joins as one broadcast add
+        y = linear_splitk(x, w)
+        return y if conv.bias is None else y + conv.bias.to(y.dtype)
+    return torch.nn.functional.linear(x, w, conv.bias)
+
+
 def _pixel_shuffle_last(x, p, c):
     """'b h w (p1 p2 c) -> b (h p1) (w p2) c' (the einops pattern of CrossMamba_fusion_2b2.py:804-808,828-829)."""
     B, H, W, _ = x.shape
@@ -322,8 +338,8 @@ class VFEFM(nn.Module):
         return x1, x2, skip
 
     def forward_up(self, x1, x2, skip):
-        x1 = self.bridge1(x1.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-        x2 = self.bridge2(x2.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        x1 = _conv1x1_last(self.bridge1, x1)
+        x2 = _conv1x1_last(self.bridge2, x2)
         skip_rev = list(reversed(skip))
         for j, layer_up in enumerate(self.layers_up):
             if j == 0:
@@ -345,4 +361,4 @@ class VFEFM(nn.Module):
         _lib.require_cuda(x1, x2)
         x1, x2, skip = self.forward_down(x1.permute(0, 2, 3, 1), x2.permute(0, 2, 3, 1))
         x = self.forward_up(x1, x2, skip)
-        return self.final_conv(x.permute(0, 3, 1, 2))
+        return _conv1x1_last(self.final_conv, x).permute(0, 3, 1, 2)
