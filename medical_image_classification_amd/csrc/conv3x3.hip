@@ -73,7 +73,7 @@ template <int CTRL> __device__ __forceinline__ float row_ror_add(float x) {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, x), CTRL, 0xF, 0xF, true));
 }
 #ifndef MS_CONV_ABL
-#define MS_CONV_ABL 0                    // timing ablations (wrong results): 1 no weight loads / 2 no halo loads / 3 neither after the first slice, 4 no products
+#define MS_CONV_ABL 0                    // timing ablations (wrong results): 1 no weight loads / 2 no halo loads / 3 neither after the first slice, 4 no products, 5 no output stores, 6 first slice only
 #endif
 #ifndef MS_CONV_PF
 #define MS_CONV_PF 1                     // slices of prefetch distance (register sets)
